@@ -1,0 +1,184 @@
+/*
+ * ldm_amd.h -- C-ABI of the MI355X (gfx950) latent-diffusion hot path.
+ *
+ * One shared library (latent-diffusion_amd/lib/libldm_amd.so), plain pointers and sizes only,
+ * no torch types.  Every device entry point launches asynchronously on the HIP stream it is given
+ * (a hipStream_t passed as void*; NULL = the default stream), never synchronises the host and never
+ * allocates device memory.  All entry points return 0 on success or a negative LDM_E* code; the text
+ * of the last failure on the calling thread is available from ldm_last_error().
+ *
+ * The reference (anenbergb/latent-diffusion, /root/reference) is pure Python: its "FFI" for this path
+ * is the set of torch ops its two hot files call.  Each declaration cites the reference lines whose
+ * arithmetic it replaces.  Layout conventions:
+ *   - activations are NHWC ("pixels x channels" row-major matrices, the transformer's (B, HW, C) view
+ *     is the same buffer), dtype LDM_BF16 or LDM_F32;
+ *   - filters are K-contiguous: [Cout][kh][kw][Cin] (see ldm_pack_weight);
+ *   - statistics, biases, norm affine parameters and scheduler tables are float32.
+ */
+#ifndef LDM_AMD_H
+#define LDM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDM_ABI_VERSION 1
+
+enum { LDM_F32 = 0, LDM_BF16 = 1 };
+
+enum {
+  LDM_OK = 0,
+  LDM_EINVAL = -1,   /* bad argument (shape / dtype / alignment / null pointer) */
+  LDM_EUNSUPPORTED = -2,
+  LDM_EHIP = -3      /* a HIP runtime call or kernel launch failed */
+};
+
+int ldm_abi_version(void);
+const char* ldm_last_error(void);
+
+/* ---------------------------------------------------------------- DDPM scheduler: host-side tables */
+
+enum { LDM_SCHED_LINEAR = 0, LDM_SCHED_COSINE = 1, LDM_SCHED_SIGMOID = 2 };
+enum { LDM_SPACING_LEADING = 0, LDM_SPACING_LINSPACE = 1, LDM_SPACING_TRAILING = 2 };
+
+/* Seven float32 tables of T entries each, written to HOST buffers.
+ * Replaces DDPMScheduler.__init__ (ldm/scheduling_ddpm.py:54-75) and get_beta_schedule (:308-357):
+ * float64 betas -> float32, then sequential float32 cumprod.  Bit-exact with the reference on CPU. */
+int ldm_ddpm_build_tables(int schedule, int T, float* betas, float* alphas_cumprod,
+                          float* sqrt_alphas_cumprod, float* sqrt_one_minus_alphas_cumprod,
+                          float* posterior_mean_coef1, float* posterior_mean_coef2, float* posterior_std);
+
+/* Inference timestep list (int64, n entries, HOST buffer).
+ * Replaces DDPMScheduler.set_timesteps (scheduling_ddpm.py:131-180).  LDM_EINVAL if n > T or n < 1. */
+int ldm_ddpm_set_timesteps(int spacing, int T, int n, int steps_offset, int64_t* timesteps);
+
+/* The five float32 scalars of one reverse step t -> s (s == -1: alpha_bar_s := 1):
+ * coef = {sqrt(1-acp_t) [table], sqrt(acp_t) [table], c1, c2, std}.
+ * Replaces the (B,1,1,1) coefficient arithmetic of predict_start_from_noise (:112-114) and
+ * q_posterior_between (:244-255) + _extract_alpha_bar (:270-282).  Tables are HOST pointers. */
+int ldm_ddpm_step_coefficients(const float* alphas_cumprod, const float* sqrt_alphas_cumprod,
+                               const float* sqrt_one_minus_alphas_cumprod, int T, int t, int s,
+                               float coef[5]);
+
+/* ------------------------------------------------------------- DDPM scheduler: device elementwise */
+
+/* prev = c1*x0 + c2*x_t + std*noise with x0 = (x_t - sigma*eps)/sqrt_acp; one coalesced pass.
+ * eps and x_t may be LDM_F32 or LDM_BF16 (promoted to float32), noise/prev/x0 are float32
+ * (scheduling_ddpm.py:207-214; results are float32 whatever the inputs are).  x0 may be NULL.
+ * n = number of elements (any n >= 0).  Replaces DDPMScheduler.step (:185-215). */
+int ldm_ddpm_step(const void* eps, int eps_dtype, const void* x_t, int x_dtype, const float* noise,
+                  float* prev, float* x0, int64_t n, const float coef[5], void* stream);
+
+/* Same update with classifier-free guidance folded in: eps = eps_u + g*(eps_c - eps_u)
+ * (train_latent_diffusion.py:589-593), then the step above.  eps_u / eps_c share eps_dtype. */
+int ldm_ddpm_step_cfg(const void* eps_u, const void* eps_c, int eps_dtype, float guidance,
+                      const void* x_t, int x_dtype, const float* noise, float* prev, float* x0,
+                      int64_t n, const float coef[5], void* stream);
+
+/* x_t = sqrt_acp[t_b]*x0 + sqrt(1-acp)[t_b]*noise, per-sample int64 t (DEVICE), tables DEVICE float32.
+ * x0/noise share `dtype`; out is float32 (the float32 (B,1,1,1) coefficients promote the result).
+ * batch samples of per_sample elements each.
+ * Replaces DDPMScheduler.add_noise + extract (scheduling_ddpm.py:81-101, :285-305). */
+int ldm_ddpm_add_noise(const void* x0, const void* noise, float* out, int dtype, const int64_t* t,
+                       const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
+                       int T, int batch, int64_t per_sample, void* stream);
+
+/* ------------------------------------------------------------------------- UNet: weight packing */
+
+/* dst[o'][kh][kw][ci] = src[o][ci][kh][kw] (src float32 OIHW / [out,in]; dst dtype LDM_BF16 or LDM_F32).
+ * glu_pairs != 0 interleaves the two halves of a GEGLU/SwiGLU projection in blocks of 16 rows
+ * (o' = 32*(o/16) + o%16 for value rows, +16 for the matching gate rows) so that value and gate of one
+ * output column land in the same lane of the MFMA epilogue (unet.py:787-790: value first half). */
+int ldm_pack_weight(const float* src, void* dst, int dst_dtype, int cout, int cin, int kh, int kw,
+                    int glu_pairs, void* stream);
+
+/* ------------------------------------------------------------------- UNet: implicit-GEMM conv/linear */
+
+enum {
+  LDM_EPI_BIAS = 1,        /* + bias[n] */
+  LDM_EPI_ROWVEC = 2,      /* + rowvec[sample(m)][n]  (time-embedding add, unet.py:727-728) */
+  LDM_EPI_RESIDUAL = 4,    /* + residual[m][n]        (unet.py:731, :593-594) */
+  LDM_EPI_SILU = 8,        /* y = y*sigmoid(y)        (time_embedding SiLU, unet.py:31, :703) */
+  LDM_EPI_GEGLU = 16,      /* out[m][j] = v*gelu_erf(g), paired columns (unet.py:787-790) */
+  LDM_EPI_SWIGLU = 32      /* out[m][j] = v*silu(g) (unet.py:765-768) */
+};
+
+typedef struct LdmConvGemm {
+  /* A operand: one or two NHWC sources, virtually concatenated along channels (torch.cat at
+   * unet.py:313/:377 is never materialised for the 1x1 shortcut).  c1 == 0: single source. */
+  const void* a0;
+  const void* a1;
+  int32_t c0, c1;
+  int32_t batch, hin, win;     /* stored spatial extent of the sources (1,1 for plain matrices) */
+  int32_t hout, wout;          /* output spatial extent */
+  int32_t ksize;               /* 1 or 3 (pad = ksize/2) */
+  int32_t stride;              /* 1 or 2 (unet.py:218 downsample) */
+  int32_t upsample;            /* 1: nearest-2x before the conv (unet.py:316-317, :385-386) */
+  /* B operand: packed filter [n][ksize*ksize*(c0+c1)] */
+  const void* w;
+  int32_t n;
+  /* epilogue */
+  int32_t epilogue;            /* LDM_EPI_* flags */
+  const float* bias;           /* [n] float32 */
+  const void* rowvec;          /* [batch][rowvec_stride] in dtype */
+  int32_t rowvec_stride;
+  const void* residual;        /* [m][n] in dtype */
+  void* out;                   /* [m][n] (or [m][n/2] with GEGLU/SWIGLU) */
+  int32_t dtype;               /* LDM_BF16 (MFMA bf16, fp32 accumulate) or LDM_F32 (exact fp32 MFMA) */
+  int32_t out_dtype;           /* dtype of out; normally == dtype */
+} LdmConvGemm;
+
+/* out = epilogue(im2col(A) @ W^T).  M = batch*hout*wout rows.  Replaces nn.Conv2d 3x3/1x1 and nn.Linear
+ * as called from ResnetBlock (unet.py:698-731), TransformerModel (:508,:521), Attention (:655-656,:683),
+ * GEGLU (:787-790), feed_forward (:579), down/upsample (:218,:317), time_embedding (:29-33). */
+int ldm_conv_gemm(const LdmConvGemm* desc, void* stream);
+
+/* --------------------------------------------------------------------------- UNet: normalisation */
+
+/* Per-(sample, group) mean and rstd over an NHWC tensor (two-source virtual concat allowed).
+ * stats[(b*groups+g)*2 + {0,1}] = {mean, rstd}.  eps 1e-5 in the reference everywhere.
+ * First half of nn.GroupNorm (unet.py:699, :705, :480, :113). */
+int ldm_groupnorm_stats(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw,
+                        int groups, float eps, float* stats, void* stream);
+
+/* out[b][p][c] = act((x-mean)*rstd*gamma[c]+beta[c]); act = SiLU if silu != 0.  Writes the (materialised)
+ * concatenation when two sources are given.  Second half of nn.GroupNorm (+ nn.SiLU, unet.py:700,:706,:114). */
+int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw,
+                        int groups, const float* stats, const float* gamma, const float* beta, int silu,
+                        void* out, void* stream);
+
+/* Row-wise LayerNorm over the last dimension (unet.py:550-551, :576), eps 1e-5. */
+int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,
+                  const float* beta, void* out, void* stream);
+
+/* -------------------------------------------------------------------------------- UNet: attention */
+
+/* out[b][i][h*d + :] = softmax(q_h k_h^T / sqrt(d)) v_h, flash-style, no mask
+ * (F.scaled_dot_product_attention at unet.py:678).  q: [batch][lq][q_stride], k/v: [batch][lk][kv_stride]
+ * (row strides in elements; head h starts at column h*d), out: [batch][lq][out_stride]. */
+int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                  int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, void* stream);
+
+/* ------------------------------------------------------------------------ UNet: first / last layers */
+
+/* Sinusoidal timestep embedding, cos first, divisor dim/2-1 (unet.py:171-173 ->
+ * diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=1)).
+ * t: DEVICE float32 [batch] (already expanded); out [batch][dim] in dtype. */
+int ldm_timestep_embedding(const float* t, int batch, int dim, void* out, int dtype, void* stream);
+
+/* conv_in (unet.py:26,:135): 3x3 pad 1 over an NCHW input with few channels -> NHWC output.
+ * x: [batch][cin][h][w] in x_dtype; w: float32 OIHW [cout][cin][3][3]; bias float32. */
+int ldm_conv_in(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,
+                int batch, int cin, int h, int wd, int cout, void* stream);
+
+/* final conv (unet.py:115,:155): 3x3 pad 1 from an NHWC activation (already GroupNorm+SiLU'ed) to an NCHW
+ * output with few channels.  w: float32 OIHW [cout][cin][3][3]. */
+int ldm_conv_out(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,
+                 int batch, int cin, int h, int wd, int cout, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_AMD_H */

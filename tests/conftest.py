@@ -1,0 +1,46 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "latent-diffusion_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+            return {k: (str(z[k]) if z[k].dtype.kind in 'US' else torch.from_numpy(z[k])) for k in z.files}
+    return load
+
+
+def seeded(shape, seed, dtype=torch.float32):
+    """Same generator recipe as tests/golden/make_golden.py."""
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed), dtype=dtype)
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))

@@ -1,0 +1,127 @@
+"""GPU parity: the fused HIP scheduler kernels (through the C-ABI) against the CPU oracle and the golden
+vectors taken from the reference.  Tolerance: bit-exact (float32 IEEE operations in the reference's order)."""
+import pytest
+import torch
+
+from conftest import seeded
+from oracle import scheduler_ref as sref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sched():
+    from ldm.scheduling_ddpm import DDPMScheduler
+    return DDPMScheduler(device=torch.device("cuda"))
+
+
+def test_tables_on_device_bit_exact(golden, sched):
+    g = golden("scheduler.npz")
+    for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
+              "posterior_mean_coef1", "posterior_mean_coef2", "posterior_std"):
+        assert getattr(sched, k).is_cuda
+        assert torch.equal(getattr(sched, k).cpu(), g[f"linear.{k}"])
+
+
+@pytest.mark.parametrize("schedule", ["linear", "cosine"])
+def test_step_golden_bit_exact(golden, schedule):
+    from ldm.scheduling_ddpm import DDPMScheduler
+    g = golden("scheduler.npz")
+    s = DDPMScheduler(beta_schedule=schedule, device=torch.device("cuda"))
+    s.set_timesteps(50, device="cuda")
+    x, e, z = g["x_t"].cuda(), g["eps"].cuda(), g["noise"].cuda()
+    for t in (980, 500, 20, 0):
+        out = s.step(e, torch.tensor(t), x, noise=z)
+        assert out.prev_sample.dtype == torch.float32
+        assert torch.equal(out.prev_sample.cpu(), g[f"step.{schedule}.{t}.prev"]), t
+        assert torch.equal(out.pred_original_sample.cpu(), g[f"step.{schedule}.{t}.x0"]), t
+
+
+def test_step_iterating_device_timesteps_no_sync(golden, sched):
+    """`for t in scheduler.timesteps` hands step() 0-d device tensors (train_latent_diffusion.py:579)."""
+    g = golden("scheduler.npz")
+    sched.set_timesteps(50)
+    x, e, z = g["x_t"].cuda(), g["eps"].cuda(), g["noise"].cuda()
+    seen = []
+    for t in sched.timesteps:
+        seen.append(sched._timestep_value(t))
+        if seen[-1] == 500:
+            out = sched.step(e, t, x, noise=z)
+            assert torch.equal(out.prev_sample.cpu(), g["step.linear.500.prev"])
+    assert seen == sref.inference_timesteps(50).tolist()
+    sched.num_inference_steps = None  # training-style: previous = t - 1
+    out = sched.step(e, 777, x, noise=z)
+    assert torch.equal(out.prev_sample.cpu(), g["step.linear.777.train.prev"])
+
+
+def test_step_bf16_inputs_promote(golden, sched):
+    g = golden("scheduler.npz")
+    sched.set_timesteps(50)
+    out = sched.step(g["eps"].bfloat16().cuda(), 500, g["x_t"].bfloat16().cuda(), noise=g["noise"].cuda())
+    assert out.prev_sample.dtype == torch.float32
+    assert torch.equal(out.prev_sample.cpu(), g["step.linear.500.bf16in.prev"])
+    assert torch.equal(out.pred_original_sample.cpu(), g["step.linear.500.bf16in.x0"])
+    # mixed: bf16 eps from the UNet, float32 latents (what generate() has after the first step)
+    out = sched.step(g["eps"].bfloat16().cuda(), 500, g["x_t"].cuda(), noise=g["noise"].cuda())
+    ref, _ = sref.step(sref.build_tables(), g["eps"].bfloat16(), 500, 480, g["x_t"], g["noise"])
+    assert torch.equal(out.prev_sample.cpu(), ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 4, 8, 8), (3, 4, 5, 7), (2, 3, 1, 1), (1, 1, 1, 1), (0, 4, 8, 8)])
+def test_step_ragged_sizes(sched, shape):
+    sched.set_timesteps(10)
+    tabs = sref.build_tables()
+    x, e, z = seeded(shape, 1), seeded(shape, 2), seeded(shape, 3)
+    for t, s in ((900, 800), (0, -1)):
+        out = sched.step(e.cuda(), t, x.cuda(), noise=z.cuda())
+        ref_prev, ref_x0 = sref.step(tabs, e, t, s, x, z)
+        assert out.prev_sample.shape == x.shape
+        assert torch.equal(out.prev_sample.cpu(), ref_prev)
+        assert torch.equal(out.pred_original_sample.cpu(), ref_x0)
+
+
+def test_step_cfg_fused(sched):
+    sched.set_timesteps(50)
+    shape = (4, 4, 32, 32)
+    x, eu, ec, z = seeded(shape, 1), seeded(shape, 2), seeded(shape, 3), seeded(shape, 4)
+    eps = eu + 7.5 * (ec - eu)  # train_latent_diffusion.py:592
+    ref, _ = sref.step(sref.build_tables(), eps, 500, 480, x, z)
+    out = sched.step(eu.cuda(), 500, x.cuda(), noise=z.cuda(), guidance=(ec.cuda(), 7.5))
+    assert torch.equal(out.prev_sample.cpu(), ref)
+
+
+def test_step_full_size_and_default_noise(sched):
+    """cfg3 shape (256,4,64,64): bit-exact against the oracle, and the default draw comes from the global
+    device generator (scheduling_ddpm.py:212)."""
+    sched.set_timesteps(50)
+    shape = (256, 4, 64, 64)
+    x, e, z = seeded(shape, 5), seeded(shape, 6), seeded(shape, 7)
+    ref, ref0 = sref.step(sref.build_tables(), e, 980, 960, x, z)
+    out = sched.step(e.cuda(), 980, x.cuda(), noise=z.cuda())
+    assert torch.equal(out.prev_sample.cpu(), ref) and torch.equal(out.pred_original_sample.cpu(), ref0)
+    torch.manual_seed(123)
+    a = sched.step(e.cuda(), 980, x.cuda()).prev_sample
+    torch.manual_seed(123)
+    zz = torch.randn(shape, dtype=torch.float32, device="cuda")
+    b = sched.step(e.cuda(), 980, x.cuda(), noise=zz).prev_sample
+    assert torch.equal(a, b)
+    # last step: std floor sqrt(1e-20) = 1e-10 and alpha_bar_{-1} := 1 -> prev == x0 up to 1e-10*noise
+    last = sched.step(e.cuda(), 0, x.cuda(), noise=z.cuda())
+    assert torch.allclose(last.prev_sample, last.pred_original_sample, atol=1e-6, rtol=0)
+
+
+def test_add_noise(golden, sched):
+    g = golden("scheduler.npz")
+    out = sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), g["add_noise.t"].cuda())
+    assert torch.equal(out.cpu(), g["add_noise.out"])
+    tabs = sref.build_tables()
+    for shape in ((32, 4, 64, 64), (3, 4, 5, 7), (2, 1, 1, 1)):
+        x, z = seeded(shape, 8), seeded(shape, 9)
+        t = torch.randint(0, 1000, (shape[0],), generator=torch.Generator().manual_seed(10))
+        out = sched.add_noise(x.cuda(), z.cuda(), t.cuda())
+        assert torch.equal(out.cpu(), sref.add_noise(tabs, x, z, t)), shape
+        outb = sched.add_noise(x.bfloat16().cuda(), z.bfloat16().cuda(), t.cuda())
+        refb = sref.add_noise(tabs, x.bfloat16(), z.bfloat16(), t)
+        assert outb.dtype == refb.dtype == torch.float32 and torch.equal(outb.cpu(), refb), shape
+    with pytest.raises(ValueError):
+        sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), torch.zeros(3, dtype=torch.long, device="cuda"))
