@@ -139,9 +139,12 @@ int ldm_conv_gemm(const LdmConvGemm* desc, void* stream);
 
 /* Per-(sample, group) mean and rstd over an NHWC tensor (two-source virtual concat allowed).
  * stats[(b*groups+g)*2 + {0,1}] = {mean, rstd}.  eps 1e-5 in the reference everywhere.
+ * Two deterministic stages (per-slab partial sums, then a fold in double); `workspace` is caller-provided
+ * DEVICE scratch of at least ldm_groupnorm_workspace_floats(batch, groups) floats.
  * First half of nn.GroupNorm (unet.py:699, :705, :480, :113). */
+int ldm_groupnorm_workspace_floats(int batch, int groups);
 int ldm_groupnorm_stats(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw,
-                        int groups, float eps, float* stats, void* stream);
+                        int groups, float eps, float* stats, float* workspace, void* stream);
 
 /* out[b][p][c] = act((x-mean)*rstd*gamma[c]+beta[c]); act = SiLU if silu != 0.  Writes the (materialised)
  * concatenation when two sources are given.  Second half of nn.GroupNorm (+ nn.SiLU, unet.py:700,:706,:114). */

@@ -1,0 +1,367 @@
+// Flash-style attention (no mask, scale 1/sqrt(d)) for the UNet's self- and cross-attention layers.
+//
+// bf16 path (head dims that are multiples of 8 up to 160: 40 / 80 / 160 in the SD-1.5-shaped model):
+//   one workgroup = 4 waves = 128 queries of one (sample, head); each wave owns 32 queries (two groups of 16) and
+//   sweeps the keys in tiles of 64.  Both products run on v_mfma_f32_16x16x32_bf16 in the TRANSPOSED
+//   orientation, S^T = K Q^T and O^T = V^T P^T: a lane then owns one query column, so the softmax is in-lane
+//   except for one 4-way max, and the S^T accumulators are, after packing to bf16, directly the B operand of the
+//   PV product (no LDS round trip for P).  V^T fragments come from ds_read_b64_tr_b16 (hardware transpose).
+//   K/V tiles are register-staged: the global loads of tile t+1 are issued before the math of tile t.
+// generic path (float32, or head dims the MFMA path does not take): one wave per query, fp32 math.
+#include "common.h"
+
+namespace ldm {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+  typedef __attribute__((ext_vector_type(2))) float f2;
+  typedef __attribute__((ext_vector_type(2))) __bf16 b2;
+  f2 v = {a, b};
+  b2 r = __builtin_convertvector(v, b2);
+  return __builtin_bit_cast(uint32_t, r);
+}
+
+struct AttnParams {
+  const void* q; const void* k; const void* v; void* out;
+  int q_stride, kv_stride, out_stride;
+  int batch, heads, lq, lk;
+  float scale_log2e;  // (1/sqrt(d)) * log2(e)
+  float scale;
+};
+
+template <int D>
+struct AttnGeom {
+  static constexpr int KS = (D + 31) / 32;             // 32-deep contraction steps of Q K^T
+  static constexpr int DK = KS * 32;
+  static constexpr int DT = (D + 15) / 16;             // 16-row tiles of O^T
+  static constexpr int KROW = DK * 2 + 16;             // bytes per key row of the K image (+16: bank spread)
+  static constexpr int VROW = (DT % 2 == 1 ? DT : DT + 1) * 32;  // odd multiple of 32 B: tr reads conflict-free
+  static constexpr int K_BYTES = 64 * KROW;
+  static constexpr int V_BYTES = 64 * VROW;
+  static constexpr int CPR = D / 8;                    // 16-byte chunks per row in global memory
+  static constexpr int NCH = (64 * CPR + 255) / 256;   // chunks per thread per tile and operand
+};
+
+template <int D>
+__global__ void __launch_bounds__(256)
+attention_bf16_kernel(const AttnParams p) {
+  using G = AttnGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* klds = smem;
+  unsigned char* vlds = smem + G::K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
+  const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
+  const bf16_t* vp = static_cast<const bf16_t*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * D;
+  bf16_t* op = static_cast<bf16_t*>(p.out) + (size_t)b * p.lq * p.out_stride + h * D;
+
+  // zero the whole LDS image once: pad columns are never written again and must not hold NaN patterns
+  for (int i = tid * 16; i < G::K_BYTES + G::V_BYTES; i += 256 * 16)
+    *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  // Q^T fragments (B operand): lane (query fr, k-group fq) holds Q[query][32*ks + 8*fq + 0..7]
+  bf16x8_t qf[2][G::KS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int qi = q0 + g * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < G::KS; ++ks) {
+      const int col = ks * 32 + fq * 8;
+      bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (qi < p.lq && col < D) z = *reinterpret_cast<const bf16x8_t*>(qp + (size_t)qi * p.q_stride + col);
+      qf[g][ks] = z;
+    }
+  }
+
+  f32x4_t o[2][G::DT];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) o[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+
+  uint4 kreg[G::NCH], vreg[G::NCH];
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+      const int idx = c * 256 + tid;
+      const int row = idx / G::CPR, ch = idx - row * G::CPR;
+      uint4 kz = make_uint4(0, 0, 0, 0), vz = kz;
+      if (idx < 64 * G::CPR && t0 + row < p.lk) {
+        kz = *reinterpret_cast<const uint4*>(kp + (size_t)(t0 + row) * p.kv_stride + ch * 8);
+        vz = *reinterpret_cast<const uint4*>(vp + (size_t)(t0 + row) * p.kv_stride + ch * 8);
+      }
+      kreg[c] = kz;
+      vreg[c] = vz;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+      const int idx = c * 256 + tid;
+      const int row = idx / G::CPR, ch = idx - row * G::CPR;
+      if (idx < 64 * G::CPR) {
+        *reinterpret_cast<uint4*>(klds + row * G::KROW + ch * 16) = kreg[c];
+        *reinterpret_cast<uint4*>(vlds + row * G::VROW + ch * 16) = vreg[c];
+      }
+    }
+  };
+
+  const int ntiles = (p.lk + 63) / 64;
+  fetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int t0 = t * 64;
+    __syncthreads();           // everyone is done reading the previous tile (and the zero fill)
+    commit();
+    __syncthreads();
+    if (t + 1 < ntiles) fetch(t0 + 64);   // in flight under the math below
+
+    // ---- S^T = K Q^T : s[g][kb] holds keys kb*16 + 4*fq + r of query fr
+    f32x4_t s[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) s[g][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) {
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(klds + (kb * 16 + fr) * G::KROW + (ks * 4 + fq) * 16);
+        s[0][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[0][ks], s[0][kb], 0, 0, 0);
+        s[1][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kb], 0, 0, 0);
+      }
+    }
+    if (t0 + 64 > p.lk) {  // ragged last tile: keys past lk get -inf
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (t0 + kb * 16 + fq * 4 + r >= p.lk) { s[0][kb][r] = -INFINITY; s[1][kb][r] = -INFINITY; }
+    }
+
+    // ---- online softmax, per query column; probabilities packed to bf16 as the B operand of P V
+    bf16x8_t pb[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float mx = s[g][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[g][kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[g], mx * p.scale_log2e);
+      const float alpha = exp2f(m_run[g] - m_new);
+      m_run[g] = m_new;
+      float psum = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[g][kb][r] * p.scale_log2e - m_new);
+          pv[kb][r] = e;
+          psum += e;
+        }
+      l_run[g] = l_run[g] * alpha + psum;
+#pragma unroll
+      for (int t2 = 0; t2 < G::DT; ++t2) {
+        o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
+      }
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        // MFMA k index 8*fq + j  <->  key (2*st)*16 + 4*fq + j (j < 4), (2*st+1)*16 + 4*fq + (j-4) (j >= 4)
+        typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+        u4 w;
+        w[0] = cvt_pk_bf16(pv[2 * st][0], pv[2 * st][1]);
+        w[1] = cvt_pk_bf16(pv[2 * st][2], pv[2 * st][3]);
+        w[2] = cvt_pk_bf16(pv[2 * st + 1][0], pv[2 * st + 1][1]);
+        w[3] = cvt_pk_bf16(pv[2 * st + 1][2], pv[2 * st + 1][3]);
+        pb[g][st] = __builtin_bit_cast(bf16x8_t, w);
+      }
+    }
+
+    // ---- O^T += V^T P^T : V^T fragments by transposed LDS reads (4 keys x 16 dims per 16-lane group)
+    const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const unsigned char* a0 = vlds + ((2 * st) * 16 + 4 * fq + tq) * G::VROW + (dt * 16 + 4 * tp) * 2;
+        const unsigned char* a1 = a0 + 16 * G::VROW;
+        const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)a0);
+        const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)a1);
+        const bf16x8_t vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[0][st], o[0][dt], 0, 0, 0);
+        o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][st], o[1][dt], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds dims dt*16 + 4*fq + 0..3 of query fr
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    float l = l_run[g];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int qi = q0 + g * 16 + fr;
+    if (qi >= p.lq) continue;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) {
+      const int col = dt * 16 + fq * 4;
+      if (col < D) {
+        uint2 w;
+        w.x = cvt_pk_bf16(o[g][dt][0] * inv, o[g][dt][1] * inv);
+        w.y = cvt_pk_bf16(o[g][dt][2] * inv, o[g][dt][3] * inv);
+        *reinterpret_cast<uint2*>(op + (size_t)qi * p.out_stride + col) = w;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- generic path
+// One wave per query (4 queries per wave in sequence, 16 per workgroup); K/V tiles of 64 keys in LDS as float.
+constexpr int GEN_QPW = 4;
+constexpr int GEN_MAXD = 256;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+attention_generic_kernel(const AttnParams p, int d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int dp = d + 1;                                   // padded row: conflict-free column walks
+  float* kt = reinterpret_cast<float*>(smem);             // [64][dp]
+  float* vt = kt + 64 * dp;                               // [64][dp]
+  float* qs = vt + 64 * dp;                               // [4 waves][GEN_QPW][d]
+  float* ps = qs + 4 * GEN_QPW * d;                       // [4 waves][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * (4 * GEN_QPW) + wave * GEN_QPW;
+  const T* qp = static_cast<const T*>(p.q) + (size_t)b * p.lq * p.q_stride + h * d;
+  const T* kp = static_cast<const T*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * d;
+  const T* vp = static_cast<const T*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * d;
+  T* op = static_cast<T*>(p.out) + (size_t)b * p.lq * p.out_stride + h * d;
+
+  float* myq = qs + wave * GEN_QPW * d;
+  float* myp = ps + wave * 64;
+  for (int i = lane; i < GEN_QPW * d; i += 64) {
+    const int qq = i / d, c = i - qq * d;
+    myq[i] = (q0 + qq < p.lq) ? Elem<T>::ld(qp + (size_t)(q0 + qq) * p.q_stride + c) : 0.f;
+  }
+  constexpr int DPL = GEN_MAXD / 64;                      // output dims per lane
+  float m_run[GEN_QPW], l_run[GEN_QPW], o[GEN_QPW][DPL];
+#pragma unroll
+  for (int qq = 0; qq < GEN_QPW; ++qq) {
+    m_run[qq] = -INFINITY; l_run[qq] = 0.f;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) o[qq][k] = 0.f;
+  }
+  for (int t0 = 0; t0 < p.lk; t0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * d; i += 256) {
+      const int row = i / d, c = i - row * d;
+      const bool ok = t0 + row < p.lk;
+      kt[row * dp + c] = ok ? Elem<T>::ld(kp + (size_t)(t0 + row) * p.kv_stride + c) : 0.f;
+      vt[row * dp + c] = ok ? Elem<T>::ld(vp + (size_t)(t0 + row) * p.kv_stride + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < GEN_QPW; ++qq) {
+      float sc = 0.f;
+      for (int c = 0; c < d; ++c) sc += myq[qq * d + c] * kt[lane * dp + c];
+      sc = (t0 + lane < p.lk) ? sc * p.scale : -INFINITY;
+      const float m_new = fmaxf(m_run[qq], wave_max(sc));
+      const float alpha = expf(m_run[qq] - m_new);
+      const float e = expf(sc - m_new);
+      l_run[qq] = l_run[qq] * alpha + wave_sum(e);
+      m_run[qq] = m_new;
+      myp[lane] = e;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        const int c = lane + 64 * k;
+        float acc = o[qq][k] * alpha;
+        if (c < d)
+          for (int j = 0; j < 64; ++j) acc += myp[j] * vt[j * dp + c];
+        o[qq][k] = acc;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int qq = 0; qq < GEN_QPW; ++qq) {
+    if (q0 + qq >= p.lq) continue;
+    const float inv = 1.0f / l_run[qq];
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c < d) Elem<T>::st(op + (size_t)(q0 + qq) * p.out_stride + c, o[qq][k] * inv);
+    }
+  }
+}
+
+template <int D>
+static int launch_mfma(const AttnParams& p, hipStream_t st) {
+  using G = AttnGeom<D>;
+  const int smem = G::K_BYTES + G::V_BYTES;
+  dim3 grid((p.lq + 127) / 128, p.heads, p.batch);
+  hipLaunchKernelGGL((attention_bf16_kernel<D>), grid, dim3(256), smem, st, p);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention(bf16 mfma)");
+  return LDM_OK;
+}
+
+}  // namespace ldm
+
+using namespace ldm;
+
+extern "C" int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                             int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_attention: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && heads >= 1 && lq >= 0 && lk >= 1 && d >= 1, "ldm_attention: bad sizes");
+  if (batch == 0 || lq == 0) return LDM_OK;
+  LDM_REQUIRE(q && k && v && out, "ldm_attention: null pointer");
+  LDM_REQUIRE(q_stride >= heads * d && kv_stride >= heads * d && out_stride >= heads * d, "ldm_attention: row strides smaller than heads*d");
+  LDM_REQUIRE(batch <= 65535 && heads <= 65535, "ldm_attention: batch/heads exceed the grid limits");
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v; p.out = out;
+  p.q_stride = q_stride; p.kv_stride = kv_stride; p.out_stride = out_stride;
+  p.batch = batch; p.heads = heads; p.lq = lq; p.lk = lk;
+  p.scale = 1.0f / sqrtf((float)d);
+  p.scale_log2e = p.scale * 1.4426950408889634f;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec_ok = aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
+                      q_stride % 8 == 0 && kv_stride % 8 == 0 && out_stride % 4 == 0;
+  if (dtype == LDM_BF16 && vec_ok) {
+    switch (d) {
+      case 40: return launch_mfma<40>(p, st);
+      case 64: return launch_mfma<64>(p, st);
+      case 80: return launch_mfma<80>(p, st);
+      case 128: return launch_mfma<128>(p, st);
+      case 160: return launch_mfma<160>(p, st);
+      default: break;
+    }
+  }
+  LDM_REQUIRE(d <= GEN_MAXD, "ldm_attention: head dim %d exceeds %d", d, GEN_MAXD);
+  const size_t smem = ((size_t)2 * 64 * (d + 1) + 4 * GEN_QPW * d + 4 * 64) * sizeof(float);
+  dim3 grid((lq + 4 * GEN_QPW - 1) / (4 * GEN_QPW), heads, batch);
+  if (smem > 64 * 1024) {
+    auto kern = dtype == LDM_BF16 ? (const void*)attention_generic_kernel<bf16_t> : (const void*)attention_generic_kernel<float>;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("ldm_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+  }
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((attention_generic_kernel<bf16_t>), grid, dim3(256), smem, st, p, d);
+  else
+    hipLaunchKernelGGL((attention_generic_kernel<float>), grid, dim3(256), smem, st, p, d);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention(generic)");
+  return LDM_OK;
+}

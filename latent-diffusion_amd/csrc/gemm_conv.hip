@@ -1,0 +1,481 @@
+// Implicit-GEMM convolution / linear layer on the gfx950 matrix cores.
+//
+//   out[m][n] = epilogue( sum_k A[m][k] * W[n][k] )      m = (sample, oh, ow), k = (kh, kw, ci)
+//
+// A is never materialised: every 16-byte chunk of a K-tile is fetched straight from the NHWC activation
+// (one or two channel-concatenated sources, optional stride 2, optional nearest-2x upsample folded into the
+// index) into LDS by LDS-DMA (global_load_lds_dwordx4), padding taps read from a zero page.  W is packed
+// [n][kh][kw][ci], so both MFMA operands are K-contiguous.  bf16 inputs, fp32 accumulation on
+// v_mfma_f32_16x16x32_bf16; the fp32 instantiation (exact fp32, v_mfma_f32_16x16x4_f32) serves the 1e-4 gate.
+//
+// LDS image of a tile: [rows][BK] bf16, 16-byte chunks XOR-swizzled by row; LDS-DMA writes lane-linear, so
+// the swizzle is applied to the per-lane SOURCE chunk and again on the fragment read (same involution).
+#include "common.h"
+
+namespace ldm {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __align__(256) unsigned char g_zero_page[256];
+
+struct ConvGemmParams {
+  const void* a0;
+  const void* a1;
+  int c0, c1, ctot;
+  int batch, hin, win, hout, wout;
+  int ksize, stride, upsample;
+  const void* w;
+  int M, N, K;
+  int epilogue;
+  const float* bias;
+  const void* rowvec;
+  int rowvec_stride;
+  const void* residual;
+  void* out;
+  int out_f32;      // out dtype is float32 (else same as compute dtype)
+  int tiles_m, tiles_n;
+};
+
+template <int CH>
+__device__ __forceinline__ int swz(int row) {
+  return CH == 8 ? (row & 7) : ((row >> 1) & 3);
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// bijective XCD remap: blocks b and b+8 share an XCD; give every XCD a contiguous run of tiles
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <typename OutT>
+__device__ __forceinline__ void epilogue_store(const ConvGemmParams& p, int m, int n, float v) {
+  // generic scalar epilogue element (bias / rowvec / residual / silu), n < N and m < M guaranteed by caller
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ void __launch_bounds__(64 * WM * WN)
+conv_gemm_bf16_kernel(const ConvGemmParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
+  constexpr int ROWB = BK * 2;               // bytes per tile row
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int A_IT = BM * CH / NT, B_IT = BN * CH / NT;
+  static_assert(BM * CH % NT == 0 && BN * CH % NT == 0, "tile/threads mismatch");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int MI = WTM / 16, NI = WTN / 16, KS = BK / 32;
+  static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+  const bf16_t* a0 = static_cast<const bf16_t*>(p.a0);
+  const bf16_t* a1 = static_cast<const bf16_t*>(p.a1);
+  const bf16_t* wq = static_cast<const bf16_t*>(p.w);
+
+  // ---- per-thread staging coordinates (fixed over the K loop)
+  const int cpos = tid % CH;                 // chunk position inside the LDS row this thread fills
+  int a_pix[A_IT], a_ih[A_IT], a_iw[A_IT], a_sw[A_IT];
+  const int hw_out = p.hout * p.wout;
+  const int hlim = p.upsample ? p.hin * 2 : p.hin;
+  const int wlim = p.upsample ? p.win * 2 : p.win;
+  const int pad = p.ksize >> 1;
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int r = (it * NT + tid) / CH;
+    const int m = m0 + r;
+    a_sw[it] = (cpos ^ swz<CH>(r)) * 8;      // source element offset inside the K-tile
+    if (m < p.M) {
+      const int b = m / hw_out, rem = m - b * hw_out;
+      const int oh = rem / p.wout, ow = rem - oh * p.wout;
+      a_pix[it] = b * p.hin * p.win;
+      a_ih[it] = oh * p.stride - pad;
+      a_iw[it] = ow * p.stride - pad;
+    } else {
+      a_pix[it] = -1;
+      a_ih[it] = a_iw[it] = 0;
+    }
+  }
+  const bf16_t* b_src[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    const int r = (it * NT + tid) / CH;
+    const int n = n0 + r;
+    b_src[it] = n < p.N ? wq + (size_t)n * p.K + (cpos ^ swz<CH>(r)) * 8 : nullptr;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    unsigned char* sa = smem + buf * STAGE;
+    unsigned char* sb = sa + A_BYTES;
+    const int k0 = kt * BK;
+    const int tap = k0 / p.ctot;             // block-uniform: ctot % BK == 0
+    const int c = k0 - tap * p.ctot;
+    const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+    const bool second = c >= p.c0;           // c0 % BK == 0
+    const bf16_t* src = second ? a1 : a0;
+    const int cs = second ? p.c1 : p.c0;
+    const int cc = second ? c - p.c0 : c;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
+      const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+      if (p.upsample) { ih >>= 1; iw >>= 1; }
+      const bf16_t* g = ok ? src + ((size_t)(a_pix[it] + ih * p.win + iw) * cs + cc + a_sw[it]) : zero;
+      glds16(g, sa + (it * NT + wave * 64) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const bf16_t* g = b_src[it] ? b_src[it] + k0 : zero;
+      glds16(g, sb + (it * NT + wave * 64) * 16);
+    }
+  };
+
+  f32x4_t acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = p.K / BK;
+
+  stage(0, 0);
+  __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        af[i] = *reinterpret_cast<const bf16x8_t*>(sa + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int row = wn * WTN + j * 16 + fr;
+        bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
+  const int epi = p.epilogue;
+  const bool glu = (epi & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
+  const int nout = glu ? p.N >> 1 : p.N;
+  const bf16_t* resid = static_cast<const bf16_t*>(p.residual);
+  const bf16_t* rowv = static_cast<const bf16_t*>(p.rowvec);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * WTM + i * 16 + fq * 4 + r;
+      if (m >= p.M) continue;
+      const int sample = (epi & LDM_EPI_ROWVEC) ? m / hw_out : 0;
+      if (!glu) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int n = n0 + wn * WTN + j * 16 + fr;
+          if (n >= p.N) continue;
+          float v = acc[i][j][r];
+          if (epi & LDM_EPI_BIAS) v += p.bias[n];
+          if (epi & LDM_EPI_ROWVEC) v += bf16_to_f32(rowv[(size_t)sample * p.rowvec_stride + n]);
+          if (epi & LDM_EPI_SILU) v = silu_f(v);
+          if (epi & LDM_EPI_RESIDUAL) v += bf16_to_f32(resid[(size_t)m * p.N + n]);
+          if (p.out_f32) static_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
+          else static_cast<bf16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_bf16(v);
+        }
+      } else {
+        if constexpr (NI % 2 == 0) {
+#pragma unroll
+          for (int j = 0; j < NI; j += 2) {
+            const int n = n0 + wn * WTN + j * 16 + fr;       // packed column of the value
+            if (n + 16 >= p.N + 0 && n >= p.N) continue;
+            if (n >= p.N) continue;
+            float val = acc[i][j][r], gate = acc[i][j + 1][r];
+            if (epi & LDM_EPI_BIAS) { val += p.bias[n]; gate += p.bias[n + 16]; }
+            const float g = (epi & LDM_EPI_GEGLU) ? gelu_erf_f(gate) : silu_f(gate);
+            const int jo = ((n0 + wn * WTN + j * 16) >> 1) + fr;  // column in the [M][N/2] output
+            const float v = val * g;
+            if (p.out_f32) static_cast<float*>(p.out)[(size_t)m * nout + jo] = v;
+            else static_cast<bf16_t*>(p.out)[(size_t)m * nout + jo] = f32_to_bf16(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- fp32
+// Exact-fp32 implicit GEMM (v_mfma_f32_16x16x4_f32: bit-for-bit a k-ordered fmaf chain).  Used for the fp32
+// parity gate, not for speed: register-staged 64x64x16 tiles, 4 waves, each a 32x32 quadrant.
+template <int BM, int BN, int BK>
+__global__ void __launch_bounds__(256)
+conv_gemm_f32_kernel(const ConvGemmParams p) {
+  constexpr int LDA = BK + 4;   // +4 floats: conflict-free column reads
+  __shared__ float sa[BM * LDA];
+  __shared__ float sb[BN * LDA];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tile = blockIdx.x;
+  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const float* a0 = static_cast<const float*>(p.a0);
+  const float* a1 = static_cast<const float*>(p.a1);
+  const float* wq = static_cast<const float*>(p.w);
+  const int hw_out = p.hout * p.wout;
+  const int hlim = p.upsample ? p.hin * 2 : p.hin;
+  const int wlim = p.upsample ? p.win * 2 : p.win;
+  const int pad = p.ksize >> 1;
+
+  // staging: BM x BK floats = BM*BK/4 float4 chunks; 256 threads -> (BM*BK/4)/256 per thread
+  constexpr int CPR = BK / 4;                       // float4 chunks per row
+  constexpr int A_IT = BM * CPR / 256, B_IT = BN * CPR / 256;
+  static_assert(BM * CPR % 256 == 0 && BN * CPR % 256 == 0, "fp32 tile/threads mismatch");
+  int a_pix[A_IT], a_ih[A_IT], a_iw[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int r = (it * 256 + tid) / CPR;
+    const int m = m0 + r;
+    if (m < p.M) {
+      const int b = m / hw_out, rem = m - b * hw_out;
+      const int oh = rem / p.wout, ow = rem - oh * p.wout;
+      a_pix[it] = b * p.hin * p.win;
+      a_ih[it] = oh * p.stride - pad;
+      a_iw[it] = ow * p.stride - pad;
+    } else {
+      a_pix[it] = -1; a_ih[it] = a_iw[it] = 0;
+    }
+  }
+  const int cq = (tid % CPR) * 4;
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int nk = p.K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int k0 = kt * BK;
+    const int tap = k0 / p.ctot;
+    const int c = k0 - tap * p.ctot;
+    const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+    const bool second = c >= p.c0;
+    const float* src = second ? a1 : a0;
+    const int cs = second ? p.c1 : p.c0;
+    const int cc = second ? c - p.c0 : c;
+    float4 va[A_IT], vb[B_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
+      const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+      if (p.upsample) { ih >>= 1; iw >>= 1; }
+      va[it] = ok ? *reinterpret_cast<const float4*>(src + ((size_t)(a_pix[it] + ih * p.win + iw) * cs + cc + cq))
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int r = (it * 256 + tid) / CPR;
+      const int n = n0 + r;
+      vb[it] = n < p.N ? *reinterpret_cast<const float4*>(wq + (size_t)n * p.K + k0 + cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int r = (it * 256 + tid) / CPR;
+      *reinterpret_cast<float4*>(&sa[r * LDA + cq]) = va[it];
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int r = (it * 256 + tid) / CPR;
+      *reinterpret_cast<float4*>(&sb[r * LDA + cq]) = vb[it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float af[2], bf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = sa[(wm * 32 + i * 16 + fr) * LDA + ks * 4 + fq];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = sb[(wn * 32 + j * 16 + fr) * LDA + ks * 4 + fq];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int epi = p.epilogue;
+  const bool glu = (epi & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
+  const int nout = glu ? p.N >> 1 : p.N;
+  const float* resid = static_cast<const float*>(p.residual);
+  const float* rowv = static_cast<const float*>(p.rowvec);
+  float* out = static_cast<float*>(p.out);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 32 + i * 16 + fq * 4 + r;
+      if (m >= p.M) continue;
+      const int sample = (epi & LDM_EPI_ROWVEC) ? m / hw_out : 0;
+      if (!glu) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + wn * 32 + j * 16 + fr;
+          if (n >= p.N) continue;
+          float v = acc[i][j][r];
+          if (epi & LDM_EPI_BIAS) v += p.bias[n];
+          if (epi & LDM_EPI_ROWVEC) v += rowv[(size_t)sample * p.rowvec_stride + n];
+          if (epi & LDM_EPI_SILU) v = v / (1.0f + expf(-v));
+          if (epi & LDM_EPI_RESIDUAL) v += resid[(size_t)m * p.N + n];
+          out[(size_t)m * p.N + n] = v;
+        }
+      } else {
+        const int n = n0 + wn * 32 + fr;
+        if (n < p.N) {
+          float val = acc[i][0][r], gate = acc[i][1][r];
+          if (epi & LDM_EPI_BIAS) { val += p.bias[n]; gate += p.bias[n + 16]; }
+          const float g = (epi & LDM_EPI_GEGLU) ? 0.5f * gate * (1.0f + erff(gate * 0.70710678118654752440f))
+                                                : gate / (1.0f + expf(-gate));
+          out[(size_t)m * nout + ((n0 + wn * 32) >> 1) + fr] = val * g;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ launch
+template <int BM, int BN, int BK, int WM, int WN>
+static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int smem = 2 * (BM + BN) * BK * 2;
+  auto kern = conv_gemm_bf16_kernel<BM, BN, BK, WM, WN>;
+  static bool attr_done = false;  // opt in to > 64 KiB of dynamic LDS once per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("ldm_conv_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), smem, st, p);
+  LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(bf16)");
+  return LDM_OK;
+}
+
+static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per_cu) {
+  const double tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
+  const double tiles = tm * tn;
+  const double useful = ((double)p.M * p.N) / (tiles * BM * BN);          // padding waste
+  const double slots = 256.0 * blocks_per_cu;
+  const double rounds = ceil(tiles / slots);
+  const double fill = tiles / (rounds * slots);                            // tail / under-fill
+  const double size_bonus = (BM * BN >= 128 * 128) ? 1.0 : 0.85;           // small tiles: less operand reuse
+  return useful * fill * size_bonus;
+}
+
+}  // namespace ldm
+
+using namespace ldm;
+
+extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
+  LDM_REQUIRE(d != nullptr, "ldm_conv_gemm: null descriptor");
+  LDM_REQUIRE(dtype_ok(d->dtype) && dtype_ok(d->out_dtype), "ldm_conv_gemm: bad dtype");
+  LDM_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == LDM_F32, "ldm_conv_gemm: out_dtype must equal dtype or be float32");
+  LDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "ldm_conv_gemm: ksize must be 1 or 3 (got %d)", d->ksize);
+  LDM_REQUIRE(d->stride == 1 || d->stride == 2, "ldm_conv_gemm: stride must be 1 or 2 (got %d)", d->stride);
+  LDM_REQUIRE(!(d->upsample && d->stride != 1), "ldm_conv_gemm: upsample with stride 2 is not a thing");
+  LDM_REQUIRE(d->batch >= 0 && d->hin >= 1 && d->win >= 1 && d->hout >= 1 && d->wout >= 1 && d->n >= 1 && d->c0 >= 1 && d->c1 >= 0,
+              "ldm_conv_gemm: bad sizes");
+  const int pad = d->ksize / 2;
+  const int hsrc = d->upsample ? 2 * d->hin : d->hin, wsrc = d->upsample ? 2 * d->win : d->win;
+  LDM_REQUIRE(d->hout == (hsrc + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (wsrc + 2 * pad - d->ksize) / d->stride + 1,
+              "ldm_conv_gemm: output extent %dx%d does not match input %dx%d (k=%d, stride=%d, upsample=%d)",
+              d->hout, d->wout, d->hin, d->win, d->ksize, d->stride, d->upsample);
+  const long long M64 = (long long)d->batch * d->hout * d->wout;
+  LDM_REQUIRE(M64 < (1LL << 31) && (long long)d->batch * d->hin * d->win < (1LL << 31), "ldm_conv_gemm: too many pixels");
+  if (M64 == 0) return LDM_OK;
+  LDM_REQUIRE(d->a0 && d->w && d->out && (d->c1 == 0 || d->a1), "ldm_conv_gemm: null pointer");
+  const int epi = d->epilogue;
+  LDM_REQUIRE(!(epi & LDM_EPI_BIAS) || d->bias, "ldm_conv_gemm: LDM_EPI_BIAS without bias");
+  LDM_REQUIRE(!(epi & LDM_EPI_ROWVEC) || (d->rowvec && d->rowvec_stride >= d->n), "ldm_conv_gemm: LDM_EPI_ROWVEC without rowvec");
+  LDM_REQUIRE(!(epi & LDM_EPI_RESIDUAL) || d->residual, "ldm_conv_gemm: LDM_EPI_RESIDUAL without residual");
+  const bool glu = (epi & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
+  LDM_REQUIRE(!glu || (d->n % 32 == 0 && !(epi & (LDM_EPI_ROWVEC | LDM_EPI_RESIDUAL | LDM_EPI_SILU))),
+              "ldm_conv_gemm: GLU epilogue needs n %% 32 == 0 and no rowvec/residual/silu");
+  LDM_REQUIRE(!((epi & LDM_EPI_GEGLU) && (epi & LDM_EPI_SWIGLU)), "ldm_conv_gemm: GEGLU and SWIGLU are exclusive");
+
+  ConvGemmParams p;
+  p.a0 = d->a0; p.a1 = d->c1 ? d->a1 : d->a0;
+  p.c0 = d->c0; p.c1 = d->c1; p.ctot = d->c0 + d->c1;
+  p.batch = d->batch; p.hin = d->hin; p.win = d->win; p.hout = d->hout; p.wout = d->wout;
+  p.ksize = d->ksize; p.stride = d->stride; p.upsample = d->upsample;
+  p.w = d->w; p.M = (int)M64; p.N = d->n; p.K = d->ksize * d->ksize * p.ctot;
+  p.epilogue = epi; p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_stride = d->rowvec_stride;
+  p.residual = d->residual; p.out = d->out;
+  p.out_f32 = d->out_dtype == LDM_F32;
+  hipStream_t st = (hipStream_t)stream;
+
+  if (d->dtype == LDM_F32) {
+    LDM_REQUIRE(p.ctot % 16 == 0 && p.c0 % 16 == 0, "ldm_conv_gemm(f32): channel counts must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
+    LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
+    p.tiles_m = (p.M + 63) / 64;
+    p.tiles_n = (p.N + 63) / 64;
+    LDM_REQUIRE(!glu || true, "");
+    hipLaunchKernelGGL((conv_gemm_f32_kernel<64, 64, 16>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+    LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(f32)");
+    return LDM_OK;
+  }
+
+  LDM_REQUIRE(p.ctot % 32 == 0 && p.c0 % 32 == 0, "ldm_conv_gemm(bf16): channel counts must be multiples of 32 (c0=%d c1=%d)", d->c0, d->c1);
+  LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
+  const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
+  if (!bk64) {
+    if (p.M <= 64 * 256 && !glu) return launch_bf16<64, 64, 32, 2, 2>(p, st);
+    return launch_bf16<128, 128, 32, 2, 2>(p, st);
+  }
+  // candidates (BM, BN, blocks/CU): GLU needs an even number of 16-column tiles per wave -> BN = 128
+  double s_128_128 = tile_score(p, 128, 128, 2);
+  double s_64_128 = tile_score(p, 64, 128, 3);
+  if (glu) return s_128_128 >= s_64_128 ? launch_bf16<128, 128, 64, 2, 2>(p, st) : launch_bf16<64, 128, 64, 2, 2>(p, st);
+  double s_128_160 = tile_score(p, 128, 160, 2);
+  double s_64_160 = tile_score(p, 64, 160, 3);
+  double best = s_128_128;
+  int pick = 0;
+  if (s_128_160 > best) { best = s_128_160; pick = 1; }
+  if (s_64_128 > best) { best = s_64_128; pick = 2; }
+  if (s_64_160 > best) { best = s_64_160; pick = 3; }
+  switch (pick) {
+    case 1: return launch_bf16<128, 160, 64, 2, 2>(p, st);
+    case 2: return launch_bf16<64, 128, 64, 2, 2>(p, st);
+    case 3: return launch_bf16<64, 160, 64, 2, 2>(p, st);
+    default: return launch_bf16<128, 128, 64, 2, 2>(p, st);
+  }
+}

@@ -1,0 +1,243 @@
+// Small kernels around the GEMM core: filter packing, sinusoidal timestep embedding, and the two
+// degenerate convolutions of the UNet (conv_in: K = 36, final conv: N = 4) that do not fit an MFMA tile.
+#include "common.h"
+
+namespace ldm {
+
+// dst[o'][kh][kw][ci] = src[o][ci][kh][kw]
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout, int cin, int taps, int glu) {
+  const int64_t total = (int64_t)cout * cin * taps;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int half = cout >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ci = (int)(i % cin);
+    const int64_t r = i / cin;
+    const int tap = (int)(r % taps);
+    const int op = (int)(r / taps);  // destination row
+    int o = op;
+    if (glu) {  // op = 32*blk + {0..15: value, 16..31: gate}
+      const int blk = op >> 5, w = op & 31;
+      o = w < 16 ? blk * 16 + w : half + blk * 16 + (w - 16);
+    }
+    Elem<T>::st(dst + i, src[((int64_t)o * cin + ci) * taps + tap]);
+  }
+}
+
+template <typename T>
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int batch, int dim, T* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim >> 1;
+  if (i >= batch * dim) return;
+  const int b = i / dim, c = i - b * dim;
+  if (c >= 2 * half) { Elem<T>::st(out + i, 0.f); return; }  // odd dim: zero pad
+  const int k = c < half ? c : c - half;
+  // float32 throughout, in the order of diffusers' get_timestep_embedding
+  const float exponent = (-9.210340371976184f * (float)k) / (float)(half - 1);
+  const float arg = t[b] * expf(exponent);
+  Elem<T>::st(out + i, c < half ? cosf(arg) : sinf(arg));  // flip_sin_to_cos: cosine half first
+}
+
+// conv_in: NCHW (few channels) -> NHWC, one thread per (pixel, 8 output channels)
+template <typename TX, typename TO, int CIN>
+__global__ void __launch_bounds__(256)
+conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
+               int batch, int h, int wd, int cout) {
+  const int chunks = cout >> 3;
+  const int64_t total = (int64_t)batch * h * wd * chunks;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)(i % chunks);
+  const int64_t pix = i / chunks;
+  const int ow = (int)(pix % wd);
+  const int oh = (int)((pix / wd) % h);
+  const int b = (int)(pix / ((int64_t)wd * h));
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bias[ch * 8 + j];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh + kh - 1;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow + kw - 1;
+        float v = 0.f;
+        if (ih >= 0 && ih < h && iw >= 0 && iw < wd) v = Elem<TX>::ld(x + (((int64_t)b * CIN + ci) * h + ih) * wd + iw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v * w[(((ch * 8 + j) * CIN + ci) * 3 + kh) * 3 + kw];
+      }
+    }
+  }
+  store8(out + pix * cout + ch * 8, acc);
+}
+
+// generic channel count (slow path)
+template <typename TX, typename TO>
+__global__ void __launch_bounds__(256)
+conv_in_generic_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                       TO* __restrict__ out, int batch, int cin, int h, int wd, int cout) {
+  const int64_t total = (int64_t)batch * h * wd * cout;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int co = (int)(i % cout);
+  const int64_t pix = i / cout;
+  const int ow = (int)(pix % wd);
+  const int oh = (int)((pix / wd) % h);
+  const int b = (int)(pix / ((int64_t)wd * h));
+  float acc = bias[co];
+  for (int ci = 0; ci < cin; ++ci)
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh + kh - 1;
+      if (ih < 0 || ih >= h) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow + kw - 1;
+        if (iw < 0 || iw >= wd) continue;
+        acc += Elem<TX>::ld(x + (((int64_t)b * cin + ci) * h + ih) * wd + iw) * w[((co * cin + ci) * 3 + kh) * 3 + kw];
+      }
+    }
+  Elem<TO>::st(out + i, acc);
+}
+
+// final conv: NHWC (many channels) -> NCHW (COUT <= 8 channels); one lane per output pixel, filter taps are
+// wave-uniform (scalar loads), the activation row is streamed 16 bytes at a time.
+template <typename TX, typename TO, int COUT>
+__global__ void __launch_bounds__(256)
+conv_out_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
+                int batch, int cin, int h, int wd) {
+  const int64_t npix = (int64_t)batch * h * wd;
+  const int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  const int ow = (int)(pix % wd);
+  const int oh = (int)((pix / wd) % h);
+  const int b = (int)(pix / ((int64_t)wd * h));
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = bias[co];
+  for (int kh = 0; kh < 3; ++kh) {
+    const int ih = oh + kh - 1;
+    if (ih < 0 || ih >= h) continue;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int iw = ow + kw - 1;
+      if (iw < 0 || iw >= wd) continue;
+      const TX* row = x + (((int64_t)b * h + ih) * wd + iw) * cin;
+      for (int c = 0; c < cin; c += 8) {
+        float v[8];
+        load8(row + c, v);
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+          const float* wp = w + ((int64_t)(co * cin + c) * 3 + kh) * 3 + kw;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[co] += v[j] * wp[j * 9];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) Elem<TO>::st(out + (((int64_t)b * COUT + co) * h + oh) * wd + ow, acc[co]);
+}
+
+static int blocks_for(int64_t n) { return (int)((n + 255) / 256); }
+
+}  // namespace ldm
+
+using namespace ldm;
+
+extern "C" int ldm_pack_weight(const float* src, void* dst, int dst_dtype, int cout, int cin, int kh, int kw,
+                               int glu_pairs, void* stream) {
+  LDM_REQUIRE(dtype_ok(dst_dtype), "ldm_pack_weight: bad dtype %d", dst_dtype);
+  LDM_REQUIRE(src && dst, "ldm_pack_weight: null pointer");
+  LDM_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1, "ldm_pack_weight: bad sizes");
+  LDM_REQUIRE(!glu_pairs || cout % 32 == 0, "ldm_pack_weight: glu_pairs needs cout %% 32 == 0 (got %d)", cout);
+  const int64_t total = (int64_t)cout * cin * kh * kw;
+  int grid = (int)((total + 255) / 256 > 65535 * 4 ? 65535 * 4 : (total + 255) / 256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dst_dtype == LDM_BF16)
+    hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, cout, cin, kh * kw, glu_pairs);
+  else
+    hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, cout, cin, kh * kw, glu_pairs);
+  LDM_HIP_CHECK_LAUNCH("ldm_pack_weight");
+  return LDM_OK;
+}
+
+extern "C" int ldm_timestep_embedding(const float* t, int batch, int dim, void* out, int dtype, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_timestep_embedding: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && dim >= 4, "ldm_timestep_embedding: bad sizes");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(t && out, "ldm_timestep_embedding: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = batch * dim;
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((timestep_embedding_kernel<bf16_t>), dim3(blocks_for(n)), dim3(256), 0, st, t, batch, dim, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((timestep_embedding_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, t, batch, dim, (float*)out);
+  LDM_HIP_CHECK_LAUNCH("ldm_timestep_embedding");
+  return LDM_OK;
+}
+
+template <typename TX, typename TO>
+static int conv_in_dispatch(const void* x, const float* w, const float* bias, void* out, int batch, int cin, int h,
+                            int wd, int cout, hipStream_t st) {
+  const int64_t npix = (int64_t)batch * h * wd;
+  if (cin == 4 && cout % 8 == 0 && aligned16(out)) {
+    hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3(blocks_for(npix * (cout / 8))), dim3(256), 0, st, (const TX*)x, w, bias,
+                       (TO*)out, batch, h, wd, cout);
+  } else {
+    hipLaunchKernelGGL((conv_in_generic_kernel<TX, TO>), dim3(blocks_for(npix * cout)), dim3(256), 0, st, (const TX*)x, w, bias,
+                       (TO*)out, batch, cin, h, wd, cout);
+  }
+  LDM_HIP_CHECK_LAUNCH("ldm_conv_in");
+  return LDM_OK;
+}
+
+extern "C" int ldm_conv_in(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,
+                           int batch, int cin, int h, int wd, int cout, void* stream) {
+  LDM_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "ldm_conv_in: bad dtype");
+  LDM_REQUIRE(batch >= 0 && cin >= 1 && h >= 1 && wd >= 1 && cout >= 1, "ldm_conv_in: bad sizes");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(x && w && bias && out, "ldm_conv_in: null pointer");
+  LDM_REQUIRE((int64_t)batch * h * wd * cout / 256 < (1LL << 31), "ldm_conv_in: too large");
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == LDM_F32 && out_dtype == LDM_F32) return conv_in_dispatch<float, float>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  if (x_dtype == LDM_F32 && out_dtype == LDM_BF16) return conv_in_dispatch<float, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  if (x_dtype == LDM_BF16 && out_dtype == LDM_F32) return conv_in_dispatch<bf16_t, float>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  return conv_in_dispatch<bf16_t, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
+}
+
+template <typename TX, typename TO>
+static int conv_out_dispatch(const void* x, const float* w, const float* bias, void* out, int batch, int cin, int h,
+                             int wd, int cout, hipStream_t st) {
+  const int64_t npix = (int64_t)batch * h * wd;
+  dim3 grid(blocks_for(npix)), block(256);
+#define LDM_CONV_OUT(CO) \
+  hipLaunchKernelGGL((conv_out_kernel<TX, TO, CO>), grid, block, 0, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd)
+  switch (cout) {
+    case 1: LDM_CONV_OUT(1); break;
+    case 2: LDM_CONV_OUT(2); break;
+    case 3: LDM_CONV_OUT(3); break;
+    case 4: LDM_CONV_OUT(4); break;
+    case 8: LDM_CONV_OUT(8); break;
+    default:
+      set_error("ldm_conv_out: cout must be 1, 2, 3, 4 or 8 (got %d)", cout);
+      return LDM_EUNSUPPORTED;
+  }
+#undef LDM_CONV_OUT
+  LDM_HIP_CHECK_LAUNCH("ldm_conv_out");
+  return LDM_OK;
+}
+
+extern "C" int ldm_conv_out(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,
+                            int batch, int cin, int h, int wd, int cout, void* stream) {
+  LDM_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "ldm_conv_out: bad dtype");
+  LDM_REQUIRE(batch >= 0 && cin >= 8 && cin % 8 == 0 && h >= 1 && wd >= 1 && cout >= 1, "ldm_conv_out: bad sizes (cin %% 8 == 0 required)");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(x && w && bias && out, "ldm_conv_out: null pointer");
+  LDM_REQUIRE(aligned16(x), "ldm_conv_out: input must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == LDM_F32 && out_dtype == LDM_F32) return conv_out_dispatch<float, float>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  if (x_dtype == LDM_F32 && out_dtype == LDM_BF16) return conv_out_dispatch<float, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  if (x_dtype == LDM_BF16 && out_dtype == LDM_F32) return conv_out_dispatch<bf16_t, float>(x, w, bias, out, batch, cin, h, wd, cout, st);
+  return conv_out_dispatch<bf16_t, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
+}

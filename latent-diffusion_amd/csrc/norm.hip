@@ -1,0 +1,300 @@
+// GroupNorm (statistics + apply, optional SiLU, two-source virtual concat) and LayerNorm on NHWC activations.
+// All of these are HBM-bound streaming kernels: 16-byte vector accesses, fp32 statistics.
+#include "common.h"
+
+namespace ldm {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLABS = 64;   // partial-sum slabs per sample (see ldm_groupnorm_stats)
+constexpr int GN_MAX_CHUNKS = 4;   // 8-channel chunks per thread -> C <= 8 * 256 * 4
+
+// Thread layout shared by the two GroupNorm kernels: CT threads across the 8-channel chunks of a pixel,
+// PIX = 256 / CT pixels per pass; a thread keeps its channel chunk(s) for the whole kernel.
+struct GnGeom {
+  int c0, c1, ctot, nchunks, ct, pix, cpg, groups, hw, slab_pixels;
+};
+
+template <typename T>
+__device__ __forceinline__ const T* gn_src(const T* a0, const T* a1, const GnGeom& g, int64_t pixel, int c, int& cs) {
+  if (c < g.c0) { cs = g.c0; return a0 + pixel * g.c0 + c; }
+  cs = g.c1;
+  return a1 + pixel * g.c1 + (c - g.c0);
+}
+
+// stage 1: per (sample, slab) partial sum / sum of squares per group -> partial[(b*slabs + s)*groups*2]
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_partial_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);  // [pix][ctot][2]
+  const int b = blockIdx.y, slab = blockIdx.x, nslabs = gridDim.x;
+  const int tid = threadIdx.x;
+  const int tp = tid / g.ct, tc = tid - tp * g.ct;
+  const bool active = tp < g.pix;
+  const int p_begin = slab * g.slab_pixels;
+  const int p_end = min(p_begin + g.slab_pixels, g.hw);
+  float s[GN_MAX_CHUNKS][8], ss[GN_MAX_CHUNKS][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_CHUNKS; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
+  if (active) {
+    for (int p = p_begin + tp; p < p_end; p += g.pix) {
+      const int64_t pixel = (int64_t)b * g.hw + p;
+#pragma unroll
+      for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
+        const int cc = tc + k * g.ct;
+        if (cc < g.nchunks) {
+          int cs;
+          float v[8];
+          load8(gn_src(a0, a1, g, pixel, cc * 8, cs), v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[k][j] += v[j]; ss[k][j] += v[j] * v[j]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
+      const int cc = tc + k * g.ct;
+      if (cc < g.nchunks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          red[((size_t)tp * g.ctot + cc * 8 + j) * 2] = s[k][j];
+          red[((size_t)tp * g.ctot + cc * 8 + j) * 2 + 1] = ss[k][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // one thread per group folds its channels over the pix rows (fixed order -> deterministic)
+  for (int grp = tid; grp < g.groups; grp += GN_THREADS) {
+    float a = 0.f, q = 0.f;
+    for (int c = grp * g.cpg; c < (grp + 1) * g.cpg; ++c)
+      for (int r = 0; r < g.pix; ++r) {
+        a += red[((size_t)r * g.ctot + c) * 2];
+        q += red[((size_t)r * g.ctot + c) * 2 + 1];
+      }
+    float* o = partial + (((size_t)b * nslabs + slab) * g.groups + grp) * 2;
+    o[0] = a;
+    o[1] = q;
+  }
+}
+
+// stage 2: fold the slabs in double, emit mean / rstd
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nslabs, int groups, int total, double count,
+                                   float eps, float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over batch*groups
+  if (i >= total) return;
+  const int b = i / groups, grp = i - b * groups;
+  double a = 0.0, q = 0.0;
+  for (int s = 0; s < nslabs; ++s) {
+    const float* o = partial + (((size_t)b * nslabs + s) * groups + grp) * 2;
+    a += (double)o[0];
+    q += (double)o[1];
+  }
+  const double mean = a / count;
+  double var = q / count - mean * mean;
+  var = var < 0.0 ? 0.0 : var;
+  stats[2 * i] = (float)mean;
+  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(GN_THREADS)
+gn_apply_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, const float* __restrict__ stats,
+                const float* __restrict__ gamma, const float* __restrict__ beta, int silu, T* __restrict__ out) {
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int tp = tid / g.ct, tc = tid - tp * g.ct;
+  if (tp >= g.pix) return;
+  const int p_begin = slab * g.slab_pixels;
+  const int p_end = min(p_begin + g.slab_pixels, g.hw);
+  float sc[GN_MAX_CHUNKS][8], sh[GN_MAX_CHUNKS][8];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
+    const int cc = tc + k * g.ct;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sc[k][j] = sh[k][j] = 0.f;
+      if (cc < g.nchunks) {
+        const int c = cc * 8 + j;
+        const float* st = stats + ((size_t)b * g.groups + c / g.cpg) * 2;
+        const float w = st[1] * gamma[c];
+        sc[k][j] = w;
+        sh[k][j] = beta[c] - st[0] * w;
+      }
+    }
+  }
+  for (int p = p_begin + tp; p < p_end; p += g.pix) {
+    const int64_t pixel = (int64_t)b * g.hw + p;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
+      const int cc = tc + k * g.ct;
+      if (cc < g.nchunks) {
+        int cs;
+        float v[8];
+        load8(gn_src(a0, a1, g, pixel, cc * 8, cs), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = v[j] * sc[k][j] + sh[k][j];
+          if (silu) y = silu_f(y);
+          v[j] = y;
+        }
+        store8(out + pixel * g.ctot + cc * 8, v);
+      }
+    }
+  }
+}
+
+static int gn_geom(int c0, int c1, int hw, int groups, int batch, GnGeom& g, int& nslabs, const char* who) {
+  LDM_REQUIRE(c0 >= 8 && c1 >= 0 && c0 % 8 == 0 && c1 % 8 == 0, "%s: channel counts must be multiples of 8 (c0=%d c1=%d)", who, c0, c1);
+  g.c0 = c0; g.c1 = c1; g.ctot = c0 + c1;
+  LDM_REQUIRE(groups >= 1 && g.ctot % groups == 0, "%s: %d channels not divisible by %d groups", who, g.ctot, groups);
+  g.nchunks = g.ctot / 8;
+  LDM_REQUIRE(g.nchunks <= GN_THREADS * GN_MAX_CHUNKS, "%s: too many channels (%d)", who, g.ctot);
+  g.ct = g.nchunks < GN_THREADS ? g.nchunks : GN_THREADS;
+  if (g.nchunks > GN_THREADS) g.ct = (g.nchunks + ((g.nchunks + GN_THREADS - 1) / GN_THREADS) - 1) / ((g.nchunks + GN_THREADS - 1) / GN_THREADS);
+  g.pix = GN_THREADS / g.ct;
+  g.cpg = g.ctot / groups;
+  g.groups = groups;
+  g.hw = hw;
+  // enough blocks to fill the chip (~8 per CU) without starving a block of work
+  int want = (2048 + batch - 1) / (batch > 0 ? batch : 1);
+  int by_work = (hw + 4 * g.pix - 1) / (4 * g.pix);
+  nslabs = want < by_work ? want : by_work;
+  if (nslabs > GN_MAX_SLABS) nslabs = GN_MAX_SLABS;
+  if (nslabs < 1) nslabs = 1;
+  g.slab_pixels = (hw + nslabs - 1) / nslabs;
+  nslabs = (hw + g.slab_pixels - 1) / g.slab_pixels;
+  return LDM_OK;
+}
+
+// ------------------------------------------------------------------------------------- LayerNorm
+constexpr int LN_MAX_CHUNKS = 8;  // per lane -> cols <= 4096
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+layernorm_kernel(const T* __restrict__ x, int64_t rows, int cols, float eps, const float* __restrict__ gamma,
+                 const float* __restrict__ beta, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunks = cols >> 3;
+  const T* xr = x + row * cols;
+  float v[LN_MAX_CHUNKS][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int cc = lane + k * 64;
+    if (cc < nchunks) {
+      load8(xr + cc * 8, v[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[k][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)cols;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int cc = lane + k * 64;
+    if (cc < nchunks) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
+  T* orow = out + row * cols;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+    const int cc = lane + k * 64;
+    if (cc < nchunks) {
+      float g[8], b[8], y[8];
+      load8(gamma + cc * 8, g);
+      load8(beta + cc * 8, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (v[k][j] - mean) * rstd * g[j] + b[j];
+      store8(orow + cc * 8, y);
+    }
+  }
+}
+
+}  // namespace ldm
+
+using namespace ldm;
+
+extern "C" int ldm_groupnorm_workspace_floats(int batch, int groups) {
+  return batch * groups * 2 * GN_MAX_SLABS;
+}
+
+extern "C" int ldm_groupnorm_stats(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw,
+                                   int groups, float eps, float* stats, float* workspace, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_groupnorm_stats: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && hw >= 1, "ldm_groupnorm_stats: bad sizes");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(batch <= 65535, "ldm_groupnorm_stats: batch %d exceeds 65535", batch);
+  LDM_REQUIRE(a0 && stats && workspace && (c1 == 0 || a1), "ldm_groupnorm_stats: null pointer");
+  GnGeom g;
+  int nslabs;
+  int rc = gn_geom(c0, c1, hw, groups, batch, g, nslabs, "ldm_groupnorm_stats");
+  if (rc) return rc;
+  LDM_REQUIRE(aligned16(a0) && (c1 == 0 || aligned16(a1)), "ldm_groupnorm_stats: inputs must be 16-byte aligned");
+  if (dtype == LDM_F32) LDM_REQUIRE(c0 % 4 == 0, "ldm_groupnorm_stats: bad c0");
+  const size_t smem = (size_t)g.pix * g.ctot * 2 * sizeof(float);
+  LDM_REQUIRE(smem <= 64 * 1024, "ldm_groupnorm_stats: %d channels need %zu bytes of LDS", g.ctot, smem);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nslabs, batch);
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((gn_partial_kernel<bf16_t>), grid, dim3(GN_THREADS), smem, st, (const bf16_t*)a0, (const bf16_t*)a1, g, workspace);
+  else
+    hipLaunchKernelGGL((gn_partial_kernel<float>), grid, dim3(GN_THREADS), smem, st, (const float*)a0, (const float*)a1, g, workspace);
+  LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_stats(partial)");
+  const int total = batch * groups;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, nslabs, groups, total,
+                     (double)hw * g.cpg, eps, stats);
+  LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_stats(finalize)");
+  return LDM_OK;
+}
+
+extern "C" int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw,
+                                   int groups, const float* stats, const float* gamma, const float* beta, int silu,
+                                   void* out, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_groupnorm_apply: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && hw >= 1, "ldm_groupnorm_apply: bad sizes");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(batch <= 65535, "ldm_groupnorm_apply: batch %d exceeds 65535", batch);
+  LDM_REQUIRE(a0 && stats && gamma && beta && out && (c1 == 0 || a1), "ldm_groupnorm_apply: null pointer");
+  GnGeom g;
+  int nslabs;
+  int rc = gn_geom(c0, c1, hw, groups, batch, g, nslabs, "ldm_groupnorm_apply");
+  if (rc) return rc;
+  LDM_REQUIRE(aligned16(a0) && aligned16(out) && (c1 == 0 || aligned16(a1)), "ldm_groupnorm_apply: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(nslabs, batch);
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), grid, dim3(GN_THREADS), 0, st, (const bf16_t*)a0, (const bf16_t*)a1, g, stats,
+                       gamma, beta, silu, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((gn_apply_kernel<float>), grid, dim3(GN_THREADS), 0, st, (const float*)a0, (const float*)a1, g, stats,
+                       gamma, beta, silu, (float*)out);
+  LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_apply");
+  return LDM_OK;
+}
+
+extern "C" int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,
+                             const float* beta, void* out, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_layernorm: bad dtype %d", dtype);
+  LDM_REQUIRE(rows >= 0 && cols >= 8 && cols % 8 == 0 && cols <= 8 * 64 * LN_MAX_CHUNKS,
+              "ldm_layernorm: cols must be a multiple of 8 in [8, %d] (got %d)", 8 * 64 * LN_MAX_CHUNKS, cols);
+  if (rows == 0) return LDM_OK;
+  LDM_REQUIRE(x && gamma && beta && out, "ldm_layernorm: null pointer");
+  LDM_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), "ldm_layernorm: buffers must be 16-byte aligned");
+  LDM_REQUIRE((rows + 3) / 4 < (1LL << 31), "ldm_layernorm: too many rows");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid((unsigned)((rows + 3) / 4));
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((layernorm_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, eps, gamma, beta, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL((layernorm_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, eps, gamma, beta, (float*)out);
+  LDM_HIP_CHECK_LAUNCH("ldm_layernorm");
+  return LDM_OK;
+}

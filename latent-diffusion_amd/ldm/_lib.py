@@ -51,8 +51,9 @@ _SIGNATURES = {
                            c_i64, c_void_p],
     "ldm_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ldm_conv_gemm": [C.POINTER(ConvGemmDesc), c_void_p],
+    "ldm_groupnorm_workspace_floats": [c_int, c_int],
     "ldm_groupnorm_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
-                            c_void_p],
+                            c_void_p, c_void_p],
     "ldm_groupnorm_apply": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                             c_void_p, c_int, c_void_p, c_void_p],
     "ldm_layernorm": [c_void_p, c_int, c_i64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],

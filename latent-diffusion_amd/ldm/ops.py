@@ -1,0 +1,215 @@
+"""Thin torch-tensor front ends of the C-ABI kernels (include/ldm_amd.h).
+
+torch supplies device memory and the current HIP stream; every computation below happens in libldm_amd.so.
+Activations are NHWC: a tensor of shape (B, H, W, C) or (B, L, C), contiguous.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, ConvGemmDesc
+
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU = _lib.EPI_BIAS, _lib.EPI_ROWVEC, _lib.EPI_RESIDUAL, _lib.EPI_SILU
+EPI_GEGLU, EPI_SWIGLU = _lib.EPI_GEGLU, _lib.EPI_SWIGLU
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {dtype} (float32 or bfloat16)")
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ldm_amd: tensors must live on an AMD GPU (there is no CPU fallback)")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) -> torch.Tensor:
+    """float32 [O, I, kh, kw] or [O, I]  ->  [O', kh*kw*I] K-contiguous filter in `dtype`."""
+    _gpu(w)
+    w = w.detach().to(torch.float32).contiguous()
+    if w.dim() == 2:
+        o, i, kh, kw = w.shape[0], w.shape[1], 1, 1
+    elif w.dim() == 1:
+        o, i, kh, kw = w.shape[0], 1, 1, 1
+    else:
+        o, i, kh, kw = w.shape
+    out = torch.empty((o, kh * kw * i), dtype=dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().ldm_pack_weight(w.data_ptr(), out.data_ptr(), dt_code(dtype), o, i, kh, kw,
+                                               1 if glu_pairs else 0, _stream(w)), "ldm_pack_weight")
+    return out
+
+
+def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
+              upsample: bool = False, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, silu: bool = False, glu: Optional[str] = None,
+              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Implicit-GEMM conv / linear.  a0 (and a1): (B, H, W, C) NHWC, or (..., C) matrices for ksize == 1.
+    w: packed [N, ksize*ksize*(C0+C1)].  Returns NHWC (B, Hout, Wout, N') / (..., N')."""
+    _gpu(a0, a1, w, bias, rowvec, residual)
+    if not a0.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
+        raise ValueError("conv_gemm: activations must be contiguous NHWC")
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    if ksize == 1 and not upsample and stride == 1:
+        lead = a0.shape[:-1]
+        rows = a0.numel() // c0
+        batch, hin, win = rows, 1, 1
+        if rowvec is not None:  # per-sample vector: keep the sample structure
+            batch = a0.shape[0]
+            hin, win = rows // batch, 1
+        hout, wout = hin, win
+        out_lead = lead
+    else:
+        if a0.dim() != 4:
+            raise ValueError("conv_gemm: 3x3 / strided / upsampled convs take (B, H, W, C) inputs")
+        batch, hin, win = a0.shape[0], a0.shape[1], a0.shape[2]
+        hs, ws = (2 * hin, 2 * win) if upsample else (hin, win)
+        pad = ksize // 2
+        hout = (hs + 2 * pad - ksize) // stride + 1
+        wout = (ws + 2 * pad - ksize) // stride + 1
+        out_lead = (batch, hout, wout)
+    if a1 is not None and a1.shape[:-1] != a0.shape[:-1]:
+        raise ValueError("conv_gemm: the two sources must agree in all but the channel dimension")
+    n = w.shape[0]
+    if w.shape[1] != ksize * ksize * (c0 + c1):
+        raise ValueError(f"conv_gemm: filter K={w.shape[1]} does not match {ksize}x{ksize}x({c0}+{c1})")
+    epi = 0
+    if bias is not None:
+        epi |= EPI_BIAS
+    if rowvec is not None:
+        epi |= EPI_ROWVEC
+    if residual is not None:
+        epi |= EPI_RESIDUAL
+    if silu:
+        epi |= EPI_SILU
+    if glu == "geglu":
+        epi |= EPI_GEGLU
+    elif glu == "swiglu":
+        epi |= EPI_SWIGLU
+    elif glu is not None:
+        raise ValueError(f"Unsupported activation function: {glu}")
+    odt = out_dtype or a0.dtype
+    nout = n // 2 if glu else n
+    out = torch.empty((*out_lead, nout), dtype=odt, device=a0.device)
+    d = ConvGemmDesc(a0=a0.data_ptr(), a1=_ptr(a1), c0=c0, c1=c1, batch=batch, hin=hin, win=win, hout=hout, wout=wout,
+                     ksize=ksize, stride=stride, upsample=1 if upsample else 0, w=w.data_ptr(), n=n, epilogue=epi,
+                     bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
+                     residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
+    with torch.cuda.device(a0.device):
+        _lib.check(_lib.load().ldm_conv_gemm(C.byref(d), _stream(a0)), "ldm_conv_gemm")
+    return out
+
+
+_gn_ws = {}
+
+
+def _gn_workspace(device, batch: int, groups: int) -> torch.Tensor:
+    need = _lib.load().ldm_groupnorm_workspace_floats(batch, groups)
+    ws = _gn_ws.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.float32, device=device)
+        _gn_ws[device] = ws
+    return ws
+
+
+def groupnorm(a0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, *, a1: Optional[torch.Tensor] = None,
+              silu: bool = False, eps: float = 1e-5) -> torch.Tensor:
+    """GroupNorm (+SiLU) over NHWC (B, H, W, C) / (B, L, C); two sources are normalised as their channel concat."""
+    _gpu(a0, a1, gamma, beta)
+    B = a0.shape[0]
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    hw = a0.numel() // (B * c0) if B else 1
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=a0.device)
+    out = torch.empty((*a0.shape[:-1], c0 + c1), dtype=a0.dtype, device=a0.device)
+    lib = _lib.load()
+    code = dt_code(a0.dtype)
+    with torch.cuda.device(a0.device):
+        st = _stream(a0)
+        ws = _gn_workspace(a0.device, B, groups)
+        _lib.check(lib.ldm_groupnorm_stats(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, stats.data_ptr(),
+                                           ws.data_ptr(), st), "ldm_groupnorm_stats")
+        _lib.check(lib.ldm_groupnorm_apply(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, stats.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, out.data_ptr(), st),
+                   "ldm_groupnorm_apply")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _gpu(x, gamma, beta)
+    cols = x.shape[-1]
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_layernorm(x.data_ptr(), dt_code(x.dtype), x.numel() // cols, cols, eps, gamma.data_ptr(),
+                                             beta.data_ptr(), out.data_ptr(), _stream(x)), "ldm_layernorm")
+    return out
+
+
+def attention(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
+    """q: (B, Lq, C); kv: (B, Lk, 2C) with K in the first C columns and V in the last (unet.py:656-657).
+    Returns (B, Lq, C) with heads merged."""
+    _gpu(q, kv)
+    B, Lq, Cq = q.shape
+    Lk = kv.shape[1]
+    if kv.shape[2] != 2 * Cq or Cq % heads:
+        raise ValueError("attention: kv must have 2*C columns and C must divide into heads")
+    d = Cq // heads
+    out = torch.empty_like(q)
+    es = q.element_size()
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().ldm_attention(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.data_ptr() + Cq * es, kv.stride(1),
+                                             out.data_ptr(), out.stride(1), dt_code(q.dtype), B, heads, Lq, Lk, d,
+                                             _stream(q)), "ldm_attention")
+    return out
+
+
+def timestep_embedding(t: torch.Tensor, dim: int, dtype: torch.dtype) -> torch.Tensor:
+    _gpu(t)
+    t = t.to(torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=dtype, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.load().ldm_timestep_embedding(t.data_ptr(), t.shape[0], dim, out.data_ptr(), dt_code(dtype), _stream(t)),
+                   "ldm_timestep_embedding")
+    return out
+
+
+def conv_in(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """x: NCHW (B, Cin, H, W); w: float32 OIHW; returns NHWC (B, H, W, Cout)."""
+    _gpu(x, w, bias)
+    x = x.contiguous()
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    out = torch.empty((B, H, W, cout), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_conv_in(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                           dt_code(out_dtype), B, cin, H, W, cout, _stream(x)), "ldm_conv_in")
+    return out
+
+
+def conv_out(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    """x: NHWC (B, H, W, Cin); w: float32 OIHW; returns NCHW (B, Cout, H, W)."""
+    _gpu(x, w, bias)
+    B, H, W, cin = x.shape
+    cout = w.shape[0]
+    out = torch.empty((B, cout, H, W), dtype=out_dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_conv_out(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                            dt_code(out_dtype), B, cin, H, W, cout, _stream(x)), "ldm_conv_out")
+    return out

@@ -44,3 +44,29 @@ def rel_l2(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def same_bits(a, b) -> bool:
+    """Bit equality with a compact failure report (never dumps tensors into the log)."""
+    a = a.detach().cpu()
+    b = b.detach().cpu()
+    if a.shape != b.shape or a.dtype != b.dtype:
+        print(f"shape/dtype mismatch: {tuple(a.shape)} {a.dtype} vs {tuple(b.shape)} {b.dtype}")
+        return False
+    if a.numel() == 0:
+        return True
+    ai = a.contiguous().view(torch.int32 if a.element_size() == 4 else (torch.int16 if a.element_size() == 2 else torch.int64))
+    bi = b.contiguous().view(ai.dtype)
+    ne = ai != bi
+    n = int(ne.sum())
+    if n:
+        idx = ne.flatten().nonzero().flatten()[:3].tolist()
+        print(f"{n}/{a.numel()} elements differ; first at flat idx {idx}: "
+              f"{[a.flatten()[i].item() for i in idx]} vs {[b.flatten()[i].item() for i in idx]}")
+    return n == 0
+
+
+def max_ulp(a, b) -> int:
+    a = a.detach().cpu().contiguous().view(torch.int32).long()
+    b = b.detach().cpu().contiguous().view(torch.int32).long()
+    return int((a - b).abs().max()) if a.numel() else 0

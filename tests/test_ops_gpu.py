@@ -1,0 +1,287 @@
+"""GPU parity of every UNet kernel, called through the C-ABI, against a plain float32 torch-CPU evaluation of the
+same operator on the same (already bf16-rounded, where applicable) inputs.
+
+Tolerances (relative L2 of the whole output): float32 kernels 2e-5 (exact-fp32 MFMA, different summation order);
+bf16 kernels 6e-3 = output rounding to bf16 (2^-9 per element, ~2.3e-3 rel-L2) plus bf16 rounding of P in attention.
+The north-star gates (1e-4 fp32 / 2e-2 bf16 per block) sit above these.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 6e-3}
+DTYPES = [torch.bfloat16, torch.float32]
+
+
+def _ops():
+    from ldm import ops
+    return ops
+
+
+def _q(x, dtype):
+    """Round to the kernel's storage dtype and return (device tensor, float32 CPU copy of the rounded values)."""
+    xd = x.to(dtype)
+    return xd.cuda(), xd.float()
+
+
+def nhwc(x):  # NCHW cpu -> NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ------------------------------------------------------------------------------------ pack_weight
+def test_pack_weight_layouts():
+    ops = _ops()
+    w = seeded((64, 32, 3, 3), 1)
+    p = ops.pack_weight(w.cuda(), torch.float32).cpu()
+    assert torch.equal(p, w.permute(0, 2, 3, 1).reshape(64, -1))
+    p = ops.pack_weight(w.cuda(), torch.bfloat16).cpu()
+    assert torch.equal(p, w.permute(0, 2, 3, 1).reshape(64, -1).bfloat16())
+    w2 = seeded((128, 40), 2)
+    p = ops.pack_weight(w2.cuda(), torch.float32, glu_pairs=True).cpu()
+    ff = 64
+    exp = torch.empty_like(w2)
+    for blk in range(ff // 16):
+        exp[32 * blk:32 * blk + 16] = w2[16 * blk:16 * blk + 16]
+        exp[32 * blk + 16:32 * blk + 32] = w2[ff + 16 * blk:ff + 16 * blk + 16]
+    assert torch.equal(p, exp)
+    b = seeded((128,), 3)
+    assert torch.equal(ops.pack_weight(b.cuda(), torch.float32, glu_pairs=True).cpu().flatten(), exp.new_tensor(
+        torch.cat([torch.cat([b[16 * k:16 * k + 16], b[ff + 16 * k:ff + 16 * k + 16]]) for k in range(ff // 16)])))
+
+
+# ------------------------------------------------------------------------------------- conv_gemm
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 128, 64), (1000, 640, 768), (77, 1280, 768), (33, 64, 32),
+                                   (4100, 160, 96), (256, 2560, 320)])
+def test_linear_bias(dtype, M, N, K):
+    ops = _ops()
+    x, xr = _q(seeded((M, K), 1), dtype)
+    w = seeded((N, K), 2) / math.sqrt(K)
+    b = seeded((N,), 3)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv_gemm(x, wp, bias=b.cuda())
+    ref = F.linear(xr, wp.float().cpu(), b)
+    assert y.shape == (M, N) and y.dtype == dtype
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_epilogues(dtype):
+    ops = _ops()
+    B, L, K, N = 3, 70, 320, 320
+    x, xr = _q(seeded((B, L, K), 1), dtype)
+    w = seeded((N, K), 2) / math.sqrt(K)
+    b = seeded((N,), 3)
+    res, resr = _q(seeded((B, L, N), 4), dtype)
+    rv, rvr = _q(seeded((B, N), 5), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    wr = wp.float().cpu()
+    y = ops.conv_gemm(x, wp, bias=b.cuda(), residual=res)
+    assert rel_l2(y, F.linear(xr, wr, b) + resr) < TOL[dtype]
+    y = ops.conv_gemm(x, wp, bias=b.cuda(), rowvec=rv)
+    assert rel_l2(y, F.linear(xr, wr, b) + rvr[:, None, :]) < TOL[dtype]
+    y = ops.conv_gemm(x, wp, bias=b.cuda(), silu=True)
+    assert rel_l2(y, F.silu(F.linear(xr, wr, b))) < TOL[dtype]
+    y = ops.conv_gemm(x, wp)  # no bias (q_proj / kv_proj)
+    assert rel_l2(y, F.linear(xr, wr)) < TOL[dtype]
+    y = ops.conv_gemm(x, wp, bias=b.cuda(), out_dtype=torch.float32)
+    assert y.dtype == torch.float32 and rel_l2(y, F.linear(xr, wr, b)) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["geglu", "swiglu"])
+def test_gated_projection(dtype, act):
+    """GEGLU / SwiGLU (unet.py:787-790 / :765-768): value = first half, gate = second half of w1_w2."""
+    ops = _ops()
+    M, C, ff = 200, 64, 256
+    x, xr = _q(seeded((M, C), 1), dtype)
+    w = seeded((2 * ff, C), 2) / math.sqrt(C)
+    b = seeded((2 * ff,), 3)
+    wp = ops.pack_weight(w.cuda(), dtype, glu_pairs=True)
+    bp = ops.pack_weight(b.cuda(), torch.float32, glu_pairs=True).flatten()
+    y = ops.conv_gemm(x, wp, bias=bp, glu=act)
+    full = F.linear(xr, w.to(dtype).float(), b)
+    val, gate = full.chunk(2, dim=-1)
+    ref = val * (F.gelu(gate) if act == "geglu" else F.silu(gate))
+    assert y.shape == (M, ff)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def _conv_ref(x_nchw, w, b, stride=1, upsample=False):
+    if upsample:
+        x_nchw = F.interpolate(x_nchw, scale_factor=2.0, mode="nearest")
+    return F.conv2d(x_nchw, w, b, stride=stride, padding=w.shape[-1] // 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,up", [
+    (2, 64, 128, 16, 16, 1, False), (1, 320, 320, 12, 10, 1, False), (3, 32, 64, 9, 7, 1, False),
+    (2, 64, 64, 16, 16, 2, False), (1, 128, 160, 7, 9, 2, False), (2, 64, 64, 8, 8, 1, True), (1, 96, 32, 5, 6, 1, True),
+])
+def test_conv3x3(dtype, B, Cin, Cout, H, W, stride, up):
+    ops = _ops()
+    x = seeded((B, Cin, H, W), 1)
+    w = seeded((Cout, Cin, 3, 3), 2) / math.sqrt(9 * Cin)
+    b = seeded((Cout,), 3)
+    xd, xr = _q(nhwc(x), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv_gemm(xd, wp, ksize=3, stride=stride, upsample=up, bias=b.cuda())
+    ref = nhwc(_conv_ref(xr.permute(0, 3, 1, 2), w.to(dtype).float(), b, stride, up))
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("ksize", [1, 3])
+def test_conv_two_sources(dtype, ksize):
+    """The channel concat of unet.py:313/:377 read in place: [hidden (c0), skip (c1)]."""
+    ops = _ops()
+    B, c0, c1, H, W, Cout = 2, 128, 64, 8, 8, 128
+    a, ar = _q(nhwc(seeded((B, c0, H, W), 1)), dtype)
+    s, sr = _q(nhwc(seeded((B, c1, H, W), 2)), dtype)
+    w = seeded((Cout, c0 + c1, ksize, ksize), 3) / math.sqrt(ksize * ksize * (c0 + c1))
+    b = seeded((Cout,), 4)
+    rv, rvr = _q(seeded((B, Cout), 5), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv_gemm(a, wp, a1=s, ksize=ksize, bias=b.cuda(), rowvec=rv)
+    cat = torch.cat([ar, sr], dim=-1).permute(0, 3, 1, 2)
+    ref = nhwc(F.conv2d(cat, w.to(dtype).float(), b, padding=ksize // 2) + rvr[:, :, None, None])
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def test_conv_gemm_rejects_bad_shapes():
+    ops = _ops()
+    x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32
+    w = torch.zeros(32, 9 * 24, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, w, ksize=3)
+    with pytest.raises(RuntimeError):
+        ops.conv_gemm(x.cpu(), w.cpu(), ksize=3)
+
+
+# ----------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 320, 16, 16, True), (3, 64, 5, 7, False), (1, 1280, 8, 8, True),
+                                            (2, 32, 32, 32, True)])
+def test_groupnorm(dtype, B, C, H, W, silu):
+    ops = _ops()
+    x, xr = _q(nhwc(seeded((B, C, H, W), 1) * 1.7 + 0.3), dtype)
+    g, be = 1 + 0.1 * seeded((C,), 2), 0.1 * seeded((C,), 3)
+    y = ops.groupnorm(x, g.cuda(), be.cuda(), 32, silu=silu)
+    ref = F.group_norm(xr.permute(0, 3, 1, 2), 32, g, be, 1e-5)
+    ref = nhwc(F.silu(ref) if silu else ref)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("c0,c1", [(640, 320), (1280, 640), (64, 32), (1280, 1280)])
+def test_groupnorm_concat_straddle(dtype, c0, c1):
+    """960 = 640+320 channels in 32 groups of 30: groups straddle the concat boundary."""
+    ops = _ops()
+    B, H, W = 2, 8, 8
+    a, ar = _q(nhwc(seeded((B, c0, H, W), 1)), dtype)
+    s, sr = _q(nhwc(seeded((B, c1, H, W), 2) * 2.0 - 0.5), dtype)
+    C = c0 + c1
+    g, be = 1 + 0.1 * seeded((C,), 3), 0.1 * seeded((C,), 4)
+    y = ops.groupnorm(a, g.cuda(), be.cuda(), 32, a1=s, silu=True)
+    cat = torch.cat([ar, sr], dim=-1).permute(0, 3, 1, 2)
+    ref = nhwc(F.silu(F.group_norm(cat, 32, g, be, 1e-5)))
+    assert y.shape == (B, H, W, C)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 640), (5, 1280), (4096, 32), (3, 64)])
+def test_layernorm(dtype, rows, C):
+    ops = _ops()
+    x, xr = _q(seeded((rows, C), 1) * 2 + 0.5, dtype)
+    g, be = 1 + 0.1 * seeded((C,), 2), 0.1 * seeded((C,), 3)
+    y = ops.layernorm(x, g.cuda(), be.cuda())
+    assert rel_l2(y, F.layer_norm(xr, (C,), g, be, 1e-5)) < TOL[dtype]
+
+
+# ------------------------------------------------------------------------------------- attention
+def _attn_ref(q, kv, heads):
+    B, L, C = q.shape
+    d = C // heads
+    k, v = kv.split(C, dim=-1)
+
+    def sp(z):
+        return z.reshape(B, -1, heads, d).permute(0, 2, 1, 3)
+
+    w = torch.softmax(sp(q) @ sp(k).transpose(-1, -2) / math.sqrt(d), dim=-1)
+    return (w @ sp(v)).permute(0, 2, 1, 3).reshape(B, L, C)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,L,Lk,C", [
+    (2, 256, 256, 320),    # d=40 self, 4 key tiles
+    (1, 1024, 1024, 320),  # d=40, many tiles, 8 query blocks
+    (2, 200, 77, 320),     # d=40 cross, ragged queries and keys
+    (2, 128, 128, 640),    # d=80
+    (1, 64, 64, 1280),     # d=160, fewer queries than a workgroup holds
+    (2, 64, 77, 1280),     # d=160 cross
+    (2, 100, 100, 32),     # d=4  (small config) -> generic path
+    (1, 50, 77, 64),       # d=8
+])
+def test_attention(dtype, B, L, Lk, C):
+    ops = _ops()
+    q, qr = _q(seeded((B, L, C), 1), dtype)
+    kv, kvr = _q(seeded((B, Lk, 2 * C), 2), dtype)
+    y = ops.attention(q, kv, 8)
+    ref = _attn_ref(qr, kvr, 8)
+    assert rel_l2(y, ref) < TOL[dtype]
+
+
+def test_attention_softmax_extremes():
+    """Large score spread: the online-softmax rescale must fire across tiles (one dominant key in a late tile)."""
+    ops = _ops()
+    B, L, C = 1, 128, 320
+    q = seeded((B, L, C), 1)
+    kv = seeded((B, 256, 2 * C), 2)
+    kv[0, 200, :C] = 6.0 * q[0, 5, :]  # key 200 (4th tile) lines up with query 5 in every head
+    qd, qr = _q(q, torch.bfloat16)
+    kvd, kvr = _q(kv, torch.bfloat16)
+    y = ops.attention(qd, kvd, 8)
+    assert rel_l2(y, _attn_ref(qr, kvr, 8)) < TOL[torch.bfloat16]
+    assert torch.isfinite(y.float()).all()
+
+
+# ---------------------------------------------------------------------------- first / last layers
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_timestep_embedding(dtype):
+    ops = _ops()
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0.0, 1.0, 20.0, 500.0, 999.0, 37.5])
+    y = ops.timestep_embedding(t.cuda(), 320, dtype)
+    ref = timestep_embedding(t, 320)
+    # sin/cos of arguments up to ~1e3: one float32 ulp of the argument is 6e-5
+    assert (y.float().cpu() - ref).abs().max() < (3e-4 if dtype == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 320), (1, 7, 9, 32)])
+def test_conv_in_out(dtype, B, H, W, C):
+    ops = _ops()
+    x = seeded((B, 4, H, W), 1)
+    w = seeded((C, 4, 3, 3), 2) / 6.0
+    b = seeded((C,), 3)
+    xd, xr = _q(x, dtype)
+    y = ops.conv_in(xd, w.cuda(), b.cuda(), dtype)
+    assert rel_l2(y, nhwc(F.conv2d(xr, w, b, padding=1))) < TOL[dtype]
+    y32 = ops.conv_in(x.cuda(), w.cuda(), b.cuda(), dtype)  # float32 latents into a bf16 net
+    assert rel_l2(y32, nhwc(F.conv2d(x, w, b, padding=1))) < TOL[dtype]
+
+    h = seeded((B, C, H, W), 4)
+    w2 = seeded((4, C, 3, 3), 5) / math.sqrt(9 * C)
+    b2 = seeded((4,), 6)
+    hd, hr = _q(nhwc(h), dtype)
+    z = ops.conv_out(hd, w2.cuda(), b2.cuda(), dtype)
+    assert z.shape == (B, 4, H, W)
+    assert rel_l2(z, F.conv2d(hr.permute(0, 3, 1, 2), w2, b2, padding=1)) < TOL[dtype]

@@ -1,9 +1,16 @@
 """GPU parity: the fused HIP scheduler kernels (through the C-ABI) against the CPU oracle and the golden
-vectors taken from the reference.  Tolerance: bit-exact (float32 IEEE operations in the reference's order)."""
+vectors taken from the reference.
+
+Tolerance: BIT-EXACT against the oracle evaluated on the same host (float32 IEEE operations in the reference's
+order).  Against the golden files (generated in the build container) the tables that go through torch's CPU
+sqrt are allowed 4 ulp and what is computed from them 1e-5 relative L2: torch's CPU sqrt is MKL's, which is not correctly
+rounded and differs between host CPUs (measured: 6/1000 entries of sqrt_alphas_cumprod differ by 1 ulp between
+the build container and the GPU box), so the reference itself is only reproducible to that level across hosts.
+betas, alphas_cumprod and the timestep lists are bit-exact against the golden files everywhere."""
 import pytest
 import torch
 
-from conftest import seeded
+from conftest import max_ulp, rel_l2, same_bits, seeded
 from oracle import scheduler_ref as sref
 
 pytestmark = pytest.mark.gpu
@@ -17,10 +24,15 @@ def sched():
 
 def test_tables_on_device_bit_exact(golden, sched):
     g = golden("scheduler.npz")
+    host = sref.build_tables("linear", 1000)
     for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod",
               "posterior_mean_coef1", "posterior_mean_coef2", "posterior_std"):
         assert getattr(sched, k).is_cuda
-        assert torch.equal(getattr(sched, k).cpu(), g[f"linear.{k}"])
+        assert same_bits(getattr(sched, k), host[k]), k
+        if k in ("betas", "alphas_cumprod"):
+            assert same_bits(getattr(sched, k), g[f"linear.{k}"]), k
+        else:
+            assert max_ulp(getattr(sched, k), g[f"linear.{k}"]) <= 4, k
 
 
 @pytest.mark.parametrize("schedule", ["linear", "cosine"])
@@ -30,11 +42,16 @@ def test_step_golden_bit_exact(golden, schedule):
     s = DDPMScheduler(beta_schedule=schedule, device=torch.device("cuda"))
     s.set_timesteps(50, device="cuda")
     x, e, z = g["x_t"].cuda(), g["eps"].cuda(), g["noise"].cuda()
+    tabs = sref.build_tables(schedule)
+    ts = sref.inference_timesteps(50)
     for t in (980, 500, 20, 0):
         out = s.step(e, torch.tensor(t), x, noise=z)
         assert out.prev_sample.dtype == torch.float32
-        assert torch.equal(out.prev_sample.cpu(), g[f"step.{schedule}.{t}.prev"]), t
-        assert torch.equal(out.pred_original_sample.cpu(), g[f"step.{schedule}.{t}.x0"]), t
+        ref_prev, ref_x0 = sref.step(tabs, g["eps"], t, sref.previous_timestep(ts, t, True), g["x_t"], g["noise"])
+        assert same_bits(out.prev_sample, ref_prev), t
+        assert same_bits(out.pred_original_sample, ref_x0), t
+        assert rel_l2(out.prev_sample, g[f"step.{schedule}.{t}.prev"]) < 1e-5, t
+        assert rel_l2(out.pred_original_sample, g[f"step.{schedule}.{t}.x0"]) < 1e-5, t
 
 
 def test_step_iterating_device_timesteps_no_sync(golden, sched):
@@ -47,11 +64,15 @@ def test_step_iterating_device_timesteps_no_sync(golden, sched):
         seen.append(sched._timestep_value(t))
         if seen[-1] == 500:
             out = sched.step(e, t, x, noise=z)
-            assert torch.equal(out.prev_sample.cpu(), g["step.linear.500.prev"])
+            ref, _ = sref.step(sref.build_tables(), g["eps"], 500, 480, g["x_t"], g["noise"])
+            assert same_bits(out.prev_sample, ref)
+            assert rel_l2(out.prev_sample, g["step.linear.500.prev"]) < 1e-5
     assert seen == sref.inference_timesteps(50).tolist()
     sched.num_inference_steps = None  # training-style: previous = t - 1
     out = sched.step(e, 777, x, noise=z)
-    assert torch.equal(out.prev_sample.cpu(), g["step.linear.777.train.prev"])
+    ref, _ = sref.step(sref.build_tables(), g["eps"], 777, 776, g["x_t"], g["noise"])
+    assert same_bits(out.prev_sample, ref)
+    assert rel_l2(out.prev_sample, g["step.linear.777.train.prev"]) < 1e-5
 
 
 def test_step_bf16_inputs_promote(golden, sched):
@@ -59,12 +80,13 @@ def test_step_bf16_inputs_promote(golden, sched):
     sched.set_timesteps(50)
     out = sched.step(g["eps"].bfloat16().cuda(), 500, g["x_t"].bfloat16().cuda(), noise=g["noise"].cuda())
     assert out.prev_sample.dtype == torch.float32
-    assert torch.equal(out.prev_sample.cpu(), g["step.linear.500.bf16in.prev"])
-    assert torch.equal(out.pred_original_sample.cpu(), g["step.linear.500.bf16in.x0"])
+    ref, ref0 = sref.step(sref.build_tables(), g["eps"].bfloat16(), 500, 480, g["x_t"].bfloat16(), g["noise"])
+    assert same_bits(out.prev_sample, ref) and same_bits(out.pred_original_sample, ref0)
+    assert rel_l2(out.prev_sample, g["step.linear.500.bf16in.prev"]) < 1e-5
     # mixed: bf16 eps from the UNet, float32 latents (what generate() has after the first step)
     out = sched.step(g["eps"].bfloat16().cuda(), 500, g["x_t"].cuda(), noise=g["noise"].cuda())
     ref, _ = sref.step(sref.build_tables(), g["eps"].bfloat16(), 500, 480, g["x_t"], g["noise"])
-    assert torch.equal(out.prev_sample.cpu(), ref)
+    assert same_bits(out.prev_sample, ref)
 
 
 @pytest.mark.parametrize("shape", [(1, 4, 8, 8), (3, 4, 5, 7), (2, 3, 1, 1), (1, 1, 1, 1), (0, 4, 8, 8)])
@@ -76,8 +98,8 @@ def test_step_ragged_sizes(sched, shape):
         out = sched.step(e.cuda(), t, x.cuda(), noise=z.cuda())
         ref_prev, ref_x0 = sref.step(tabs, e, t, s, x, z)
         assert out.prev_sample.shape == x.shape
-        assert torch.equal(out.prev_sample.cpu(), ref_prev)
-        assert torch.equal(out.pred_original_sample.cpu(), ref_x0)
+        assert same_bits(out.prev_sample, ref_prev)
+        assert same_bits(out.pred_original_sample, ref_x0)
 
 
 def test_step_cfg_fused(sched):
@@ -87,7 +109,7 @@ def test_step_cfg_fused(sched):
     eps = eu + 7.5 * (ec - eu)  # train_latent_diffusion.py:592
     ref, _ = sref.step(sref.build_tables(), eps, 500, 480, x, z)
     out = sched.step(eu.cuda(), 500, x.cuda(), noise=z.cuda(), guidance=(ec.cuda(), 7.5))
-    assert torch.equal(out.prev_sample.cpu(), ref)
+    assert same_bits(out.prev_sample, ref)
 
 
 def test_step_full_size_and_default_noise(sched):
@@ -98,13 +120,13 @@ def test_step_full_size_and_default_noise(sched):
     x, e, z = seeded(shape, 5), seeded(shape, 6), seeded(shape, 7)
     ref, ref0 = sref.step(sref.build_tables(), e, 980, 960, x, z)
     out = sched.step(e.cuda(), 980, x.cuda(), noise=z.cuda())
-    assert torch.equal(out.prev_sample.cpu(), ref) and torch.equal(out.pred_original_sample.cpu(), ref0)
+    assert same_bits(out.prev_sample, ref) and same_bits(out.pred_original_sample, ref0)
     torch.manual_seed(123)
     a = sched.step(e.cuda(), 980, x.cuda()).prev_sample
     torch.manual_seed(123)
     zz = torch.randn(shape, dtype=torch.float32, device="cuda")
     b = sched.step(e.cuda(), 980, x.cuda(), noise=zz).prev_sample
-    assert torch.equal(a, b)
+    assert same_bits(a, b)
     # last step: std floor sqrt(1e-20) = 1e-10 and alpha_bar_{-1} := 1 -> prev == x0 up to 1e-10*noise
     last = sched.step(e.cuda(), 0, x.cuda(), noise=z.cuda())
     assert torch.allclose(last.prev_sample, last.pred_original_sample, atol=1e-6, rtol=0)
@@ -113,15 +135,16 @@ def test_step_full_size_and_default_noise(sched):
 def test_add_noise(golden, sched):
     g = golden("scheduler.npz")
     out = sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), g["add_noise.t"].cuda())
-    assert torch.equal(out.cpu(), g["add_noise.out"])
     tabs = sref.build_tables()
+    assert same_bits(out, sref.add_noise(tabs, g["x_t"], g["noise"], g["add_noise.t"]))
+    assert rel_l2(out, g["add_noise.out"]) < 1e-5
     for shape in ((32, 4, 64, 64), (3, 4, 5, 7), (2, 1, 1, 1)):
         x, z = seeded(shape, 8), seeded(shape, 9)
         t = torch.randint(0, 1000, (shape[0],), generator=torch.Generator().manual_seed(10))
         out = sched.add_noise(x.cuda(), z.cuda(), t.cuda())
-        assert torch.equal(out.cpu(), sref.add_noise(tabs, x, z, t)), shape
+        assert same_bits(out, sref.add_noise(tabs, x, z, t)), shape
         outb = sched.add_noise(x.bfloat16().cuda(), z.bfloat16().cuda(), t.cuda())
         refb = sref.add_noise(tabs, x.bfloat16(), z.bfloat16(), t)
-        assert outb.dtype == refb.dtype == torch.float32 and torch.equal(outb.cpu(), refb), shape
+        assert outb.dtype == refb.dtype == torch.float32 and same_bits(outb, refb), shape
     with pytest.raises(ValueError):
         sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), torch.zeros(3, dtype=torch.long, device="cuda"))
