@@ -171,6 +171,10 @@ int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int
  * t: DEVICE float32 [batch] (already expanded); out [batch][dim] in dtype. */
 int ldm_timestep_embedding(const float* t, int batch, int dim, void* out, int dtype, void* stream);
 
+/* y = x * sigmoid(x) elementwise (nn.SiLU in front of ResnetBlock.time, unet.py:703).  Small tensors only:
+ * every other SiLU of the model is fused into a GroupNorm or GEMM kernel. */
+int ldm_silu(const void* x, void* y, int dtype, int64_t n, void* stream);
+
 /* conv_in (unet.py:26,:135): 3x3 pad 1 over an NCHW input with few channels -> NHWC output.
  * x: [batch][cin][h][w] in x_dtype; w: float32 OIHW [cout][cin][3][3]; bias float32. */
 int ldm_conv_in(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,

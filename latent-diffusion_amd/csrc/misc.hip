@@ -139,6 +139,12 @@ conv_out_kernel(const TX* __restrict__ x, const float* __restrict__ w, const flo
   for (int co = 0; co < COUT; ++co) Elem<TO>::st(out + (((int64_t)b * COUT + co) * h + oh) * wd + ow, acc[co]);
 }
 
+template <typename T>
+__global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = Elem<T>::ld(x + i); Elem<T>::st(y + i, v / (1.0f + expf(-v))); }
+}
+
 static int blocks_for(int64_t n) { return (int)((n + 255) / 256); }
 
 }  // namespace ldm
@@ -240,4 +246,16 @@ extern "C" int ldm_conv_out(const void* x, int x_dtype, const float* w, const fl
   if (x_dtype == LDM_F32 && out_dtype == LDM_BF16) return conv_out_dispatch<float, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
   if (x_dtype == LDM_BF16 && out_dtype == LDM_F32) return conv_out_dispatch<bf16_t, float>(x, w, bias, out, batch, cin, h, wd, cout, st);
   return conv_out_dispatch<bf16_t, bf16_t>(x, w, bias, out, batch, cin, h, wd, cout, st);
+}
+
+extern "C" int ldm_silu(const void* x, void* y, int dtype, int64_t n, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_silu: bad dtype %d", dtype);
+  LDM_REQUIRE(n >= 0 && n / 256 < (1LL << 31), "ldm_silu: bad size");
+  if (n == 0) return LDM_OK;
+  LDM_REQUIRE(x && y, "ldm_silu: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LDM_BF16) hipLaunchKernelGGL((silu_kernel<bf16_t>), dim3(blocks_for(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+  else hipLaunchKernelGGL((silu_kernel<float>), dim3(blocks_for(n)), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  LDM_HIP_CHECK_LAUNCH("ldm_silu");
+  return LDM_OK;
 }

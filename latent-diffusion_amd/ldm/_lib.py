@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ldm_attention": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_void_p],
     "ldm_timestep_embedding": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
+    "ldm_silu": [c_void_p, c_void_p, c_int, c_i64, c_void_p],
     "ldm_conv_in": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                     c_void_p],
     "ldm_conv_out": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

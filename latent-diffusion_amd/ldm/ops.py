@@ -171,7 +171,7 @@ def attention(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
     if kv.shape[2] != 2 * Cq or Cq % heads:
         raise ValueError("attention: kv must have 2*C columns and C must divide into heads")
     d = Cq // heads
-    out = torch.empty_like(q)
+    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     es = q.element_size()
     with torch.cuda.device(q.device):
         _lib.check(_lib.load().ldm_attention(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.data_ptr() + Cq * es, kv.stride(1),
@@ -212,4 +212,13 @@ def conv_out(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype: to
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_conv_out(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                             dt_code(out_dtype), B, cin, H, W, cout, _stream(x)), "ldm_conv_out")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _gpu(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_silu(x.data_ptr(), out.data_ptr(), dt_code(x.dtype), x.numel(), _stream(x)), "ldm_silu")
     return out

@@ -1,0 +1,413 @@
+"""SD-1.5-shaped conditional UNet denoiser whose forward runs on MI355X HIP kernels.
+
+Drop-in for ``ldm/unet.py`` of anenbergb/latent-diffusion: same public classes, constructor arguments and defaults
+(unet.py:10-22), same ``forward(sample, timestep, encoder_hidden_states)`` (:118-156), same ``state_dict()`` key names
+and shapes (so the reference's checkpoints load), default PyTorch parameter initialisation.  The torch layers inside
+the modules below exist only to own the parameters under the reference's names; none of them is ever called.  The
+arithmetic is a straight-line schedule of C-ABI kernel launches (``ops.py`` -> ``libldm_amd.so``):
+
+* activations are NHWC in the compute dtype (bf16 with fp32 accumulation, or exact fp32), so the
+  NCHW<->(B, HW, C) rearranges of TransformerModel (:509-520) vanish and 1x1 convs are plain GEMMs;
+* every conv / linear is the MFMA implicit-GEMM kernel with bias, time-embedding add, residual add, SiLU and
+  GEGLU/SwiGLU fused as epilogues; ``torch.cat`` of the up path (:313, :377) and ``F.interpolate`` (:316, :385)
+  are folded into the operand gather; the 22 per-block time projections (:703, :727) run as ONE GEMM;
+* q and kv projections of self-attention are one GEMM; attention is flash-style on the matrix cores.
+
+The reference's quirks are reproduced: no skip around TransformerModel, no residual around
+the feed-forward, attn2 always 8 heads, K = first half of kv_proj, GEGLU value = first half, GN/LN eps 1e-5.
+
+There is no CPU fallback and (this round) no backward: calling with autograd recording enabled raises.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Union
+
+import torch
+from torch import nn
+
+from . import ops
+
+
+def _j(prefix: str, name: str) -> str:
+    return f"{prefix}.{name}" if prefix else name
+
+
+def _seq(*mods):
+    return nn.Sequential(*mods)
+
+
+def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
+    """bf16 storage / fp32 accumulation for bf16 inputs or under bf16 autocast, exact fp32 otherwise."""
+    if x.dtype == torch.bfloat16:
+        return torch.bfloat16
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        return torch.bfloat16
+    if x.dtype == torch.float32:
+        return torch.float32
+    raise TypeError(f"ldm_amd: unsupported dtype {x.dtype} (float32 or bfloat16)")
+
+
+# --------------------------------------------------------------------------------------- packed weights
+def pack_tree(root: nn.Module, dtype: torch.dtype) -> dict:
+    """Derived, K-contiguous copies of every filter under ``root`` in the compute dtype, keyed by module path.
+    Checkpoint layout stays PyTorch's ([out, in, kh, kw]); these are rebuilt when a parameter changes."""
+    P = {}
+
+    def f32(p):
+        return p.detach().to(torch.float32).contiguous()
+
+    with torch.no_grad():
+        for name, mod in root.named_modules():
+            if getattr(mod, "_ldm_raw", False):       # conv_in / final conv keep float32 OIHW filters
+                P[name + ".w"] = f32(mod.weight)
+                P[name + ".b"] = f32(mod.bias)
+            elif getattr(mod, "_ldm_skip", False):    # covered by a fused filter below
+                continue
+            elif isinstance(mod, (nn.Conv2d, nn.Linear)):
+                glu = name.endswith("w1_w2")
+                P[name + ".w"] = ops.pack_weight(mod.weight, dtype, glu_pairs=glu)
+                if mod.bias is not None:
+                    P[name + ".b"] = ops.pack_weight(mod.bias, torch.float32, glu_pairs=True).flatten() if glu \
+                        else f32(mod.bias)
+            elif isinstance(mod, (nn.GroupNorm, nn.LayerNorm)):
+                P[name + ".g"] = f32(mod.weight)
+                P[name + ".b"] = f32(mod.bias)
+            if isinstance(mod, Attention) and mod.fused_qkv:
+                P[_j(name, "qkv.w")] = ops.pack_weight(torch.cat([mod.q_proj.weight, mod.kv_proj.weight], 0), dtype)
+        resnets = [(n, m) for n, m in root.named_modules() if isinstance(m, ResnetBlock)]
+        if isinstance(root, UNet) and resnets:
+            # all time projections (unet.py:703) as one filter; each resnet reads its column slice
+            P["time_all.w"] = ops.pack_weight(torch.cat([m.time[1].weight for _, m in resnets], 0), dtype)
+            P["time_all.b"] = f32(torch.cat([m.time[1].bias for _, m in resnets], 0))
+            off = 0
+            for n, m in resnets:
+                P[n + ".time_off"] = off
+                off += m.out_channels
+    return P
+
+
+class _HipModule(nn.Module):
+    """Caches the packed weights of the tree rooted here until any parameter changes (optimizer step, load)."""
+
+    def _packed_for(self, dtype: torch.dtype) -> dict:
+        ver = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        cache = self.__dict__.setdefault("_ldm_cache", {})
+        if cache.get("ver") != ver:
+            cache.clear()
+            cache["ver"] = ver
+        if dtype not in cache:
+            cache[dtype] = pack_tree(self, dtype)
+        return cache[dtype]
+
+    def _check_call(self, x: torch.Tensor):
+        if not x.is_cuda:
+            raise RuntimeError("ldm_amd: tensors must live on an AMD GPU (there is no CPU fallback)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("ldm_amd: the HIP backward is not built yet; call under torch.no_grad() / "
+                                      "torch.inference_mode()")
+        p = next(self.parameters(), None)
+        if p is not None and p.device != x.device:
+            raise RuntimeError("ldm_amd: parameters and input are on different devices")
+
+
+def _to_nhwc(x: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
+    return x.to(dt).permute(0, 2, 3, 1).contiguous()
+
+
+def _to_nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------- kernel schedules
+def run_resnet(P, n: str, r: "ResnetBlock", x, skip, rowvec):
+    """unet.py:720-731 with x (and skip) NHWC; the concat [x, skip] is only ever read in place.
+    rowvec: (B, Cout) view of Linear(SiLU(temb)) (bias included)."""
+    g = r.norm_num_groups
+    a = ops.groupnorm(x, P[_j(n, "visual.0.g")], P[_j(n, "visual.0.b")], g, a1=skip, silu=True)
+    v = ops.conv_gemm(a, P[_j(n, "visual.2.w")], ksize=3, bias=P[_j(n, "visual.2.b")], rowvec=rowvec)
+    a = ops.groupnorm(v, P[_j(n, "layers.0.g")], P[_j(n, "layers.0.b")], g, silu=True)
+    if r.conv_shortcut is not None:
+        res = ops.conv_gemm(x, P[_j(n, "conv_shortcut.w")], a1=skip, bias=P[_j(n, "conv_shortcut.b")])
+    else:
+        res = x
+    return ops.conv_gemm(a, P[_j(n, "layers.3.w")], ksize=3, bias=P[_j(n, "layers.3.b")], residual=res)
+
+
+def run_attention(P, n: str, a: "Attention", x, ctx, residual=None):
+    """unet.py:641-684.  ctx None = self-attention (one fused q|k|v GEMM)."""
+    C = a.inner_dim
+    if ctx is None and a.fused_qkv:
+        qkv = ops.conv_gemm(x, P[_j(n, "qkv.w")])
+        q, kv = qkv[..., :C], qkv[..., C:]
+    else:
+        q = ops.conv_gemm(x, P[_j(n, "q_proj.w")])
+        kv = ops.conv_gemm(x if ctx is None else ctx, P[_j(n, "kv_proj.w")])
+    att = ops.attention(q, kv, a.num_heads)
+    return ops.conv_gemm(att, P[_j(n, "output_proj.0.w")], bias=P[_j(n, "output_proj.0.b")], residual=residual)
+
+
+def run_transformer_block(P, n: str, blk: "TransformerBlock", x, ctx):
+    """unet.py:593-596 on (B, L, C)."""
+    y = ops.layernorm(x, P[_j(n, "norm1.g")], P[_j(n, "norm1.b")])
+    x1 = run_attention(P, _j(n, "attn1"), blk.attn1, y, None, residual=x)
+    y = ops.layernorm(x1, P[_j(n, "norm2.g")], P[_j(n, "norm2.b")])
+    x2 = run_attention(P, _j(n, "attn2"), blk.attn2, y, ctx, residual=x1)
+    y = ops.layernorm(x2, P[_j(n, "feed_forward.0.g")], P[_j(n, "feed_forward.0.b")])
+    y = ops.conv_gemm(y, P[_j(n, "feed_forward.1.w1_w2.w")], bias=P[_j(n, "feed_forward.1.w1_w2.b")], glu=blk.activation_fn)
+    return ops.conv_gemm(y, P[_j(n, "feed_forward.3.w")], bias=P[_j(n, "feed_forward.3.b")])  # no residual (:595)
+
+
+def run_transformer_model(P, n: str, t: "TransformerModel", h, ctx):
+    """unet.py:507-521 on the NHWC activation viewed as (B, HW, C)."""
+    B, H, W, C = h.shape
+    x = ops.groupnorm(h, P[_j(n, "norm.g")], P[_j(n, "norm.b")], t.norm_num_groups)
+    x = ops.conv_gemm(x.view(B, H * W, C), P[_j(n, "proj_in.w")], bias=P[_j(n, "proj_in.b")])
+    for k, blk in enumerate(t.transformer_blocks):
+        x = run_transformer_block(P, _j(n, f"transformer_blocks.{k}"), blk, x, ctx)
+    x = ops.conv_gemm(x, P[_j(n, "proj_out.w")], bias=P[_j(n, "proj_out.b")])  # no skip connection (:521)
+    return x.view(B, H, W, C)
+
+
+# -------------------------------------------------------------------------------------- public modules
+class ResnetBlock(_HipModule):
+    """unet.py:687-731.  forward(input_tensor NCHW, temb (B, temb_channels)) -> NCHW."""
+
+    def __init__(self, in_channels: int, out_channels: Optional[int] = None, temb_channels: int = 512,
+                 norm_num_groups: int = 32, dropout: float = 0.0):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        if dropout != 0.0:
+            raise NotImplementedError("ldm_amd: dropout > 0 is not supported (the reference trainer uses 0)")
+        self.visual = _seq(nn.GroupNorm(norm_num_groups, in_channels), nn.Identity(),
+                           nn.Conv2d(in_channels, out_channels, 3, padding=1))
+        self.time = _seq(nn.Identity(), nn.Linear(temb_channels, out_channels))
+        self.layers = _seq(nn.GroupNorm(norm_num_groups, out_channels), nn.Identity(), nn.Identity(),
+                           nn.Conv2d(out_channels, out_channels, 3, padding=1))
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+        self.in_channels, self.out_channels, self.norm_num_groups = in_channels, out_channels, int(norm_num_groups)
+
+    def forward(self, input_tensor: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
+        self._check_call(input_tensor)
+        dt = compute_dtype_of(input_tensor)
+        P = self._packed_for(dt)
+        rowvec = ops.conv_gemm(ops.silu(temb.to(dt)), P["time.1.w"], bias=P["time.1.b"])
+        return _to_nchw(run_resnet(P, "", self, _to_nhwc(input_tensor, dt), None, rowvec))
+
+
+class Attention(_HipModule):
+    """unet.py:599-684.  forward(in_features (B, L, C), cross_features=None) -> (B, L, inner_dim)."""
+
+    def __init__(self, query_dim: int, num_heads: int = 8, dim_head: int = 64, dropout: float = 0.0,
+                 cross_attention_dim: Optional[int] = None):
+        super().__init__()
+        self.query_dim, self.num_heads, self.dim_head, self.dropout = query_dim, num_heads, dim_head, dropout
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.inner_dim = dim_head * num_heads
+        self.q_proj = nn.Linear(query_dim, self.inner_dim, bias=False)
+        self.kv_proj = nn.Linear(self.cross_attention_dim, self.inner_dim * 2, bias=False)
+        self.output_proj = _seq(nn.Linear(self.inner_dim, self.inner_dim), nn.Identity())
+        self.fused_qkv = self.cross_attention_dim == query_dim
+
+    def self_attention_only(self):
+        """Used by TransformerBlock for attn1: only the fused q|k|v filter is packed."""
+        self.q_proj._ldm_skip = True
+        self.kv_proj._ldm_skip = True
+        return self
+
+    def forward(self, in_features: torch.Tensor, cross_features: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_call(in_features)
+        dt = compute_dtype_of(in_features)
+        P = self._packed_for(dt)
+        ctx = None if cross_features is None else cross_features.to(dt).contiguous()
+        return run_attention(P, "", self, in_features.to(dt).contiguous(), ctx)
+
+
+class _GatedProjection(nn.Module):
+    """Parameter holder for GEGLU / SwiGLU (unet.py:734-790): one Linear(dim, 2*d_ff) named w1_w2."""
+
+    def __init__(self, dim: int, d_ff: int, bias: bool = True):
+        super().__init__()
+        self.w1_w2 = nn.Linear(dim, 2 * d_ff, bias=bias)
+
+
+class GEGLU(_GatedProjection):
+    pass
+
+
+class SwiGLU(_GatedProjection):
+    pass
+
+
+class TransformerBlock(_HipModule):
+    """unet.py:524-596.  forward(hidden_states (B, L, C), encoder_hidden_states (B, S, Dc)) -> (B, L, C)."""
+
+    def __init__(self, in_channels: int, num_attention_heads: int, cross_attention_dim: int, dropout=0.0,
+                 activation_fn: str = "geglu", feed_forward_mult: int = 4):
+        super().__init__()
+        assert in_channels % num_attention_heads == 0, "in_channels must be divisible by num_attention_heads"
+        self.attention_head_dim = in_channels // num_attention_heads
+        self.norm1 = nn.LayerNorm(in_channels)
+        self.norm2 = nn.LayerNorm(in_channels)
+        self.attn1 = Attention(in_channels, num_attention_heads, self.attention_head_dim, dropout).self_attention_only()
+        # attn2 is built without num_heads in the reference: always 8 heads (unet.py:559-564, default :619)
+        self.attn2 = Attention(in_channels, dim_head=self.attention_head_dim, dropout=dropout,
+                               cross_attention_dim=cross_attention_dim)
+        ff_dim = int(feed_forward_mult * in_channels)
+        if activation_fn == "geglu":
+            act = GEGLU(in_channels, ff_dim)
+        elif activation_fn == "swiglu":
+            act = SwiGLU(in_channels, ff_dim)
+        else:
+            raise ValueError(f"Unsupported activation function: {activation_fn}")
+        self.activation_fn = activation_fn
+        self.feed_forward = _seq(nn.LayerNorm(in_channels), act, nn.Identity(), nn.Linear(ff_dim, in_channels))
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        self._check_call(hidden_states)
+        dt = compute_dtype_of(hidden_states)
+        P = self._packed_for(dt)
+        return run_transformer_block(P, "", self, hidden_states.to(dt).contiguous(),
+                                     encoder_hidden_states.to(dt).contiguous())
+
+
+class TransformerModel(_HipModule):
+    """unet.py:451-521.  forward(hidden_states NCHW, encoder_hidden_states (B, S, Dc)) -> NCHW."""
+
+    def __init__(self, in_channels: int = 320, num_attention_heads: int = 16, num_layers: int = 1,
+                 cross_attention_dim: int = 768, dropout: float = 0.0, norm_num_groups: int = 32,
+                 feed_forward_mult: int = 4, activation_fn: str = "geglu"):
+        super().__init__()
+        assert in_channels % num_attention_heads == 0, "in_channels must be divisible by num_attention_heads"
+        self.in_channels, self.norm_num_groups = in_channels, int(norm_num_groups)
+        self.norm = nn.GroupNorm(norm_num_groups, in_channels)
+        self.proj_in = nn.Conv2d(in_channels, in_channels, 1)
+        self.transformer_blocks = nn.ModuleList([
+            TransformerBlock(in_channels, num_attention_heads, cross_attention_dim, dropout, activation_fn, feed_forward_mult)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Conv2d(in_channels, in_channels, 1)
+
+    def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None) -> torch.Tensor:
+        self._check_call(hidden_states)
+        dt = compute_dtype_of(hidden_states)
+        P = self._packed_for(dt)
+        return _to_nchw(run_transformer_model(P, "", self, _to_nhwc(hidden_states, dt),
+                                              encoder_hidden_states.to(dt).contiguous()))
+
+
+class _Stage(nn.Module):
+    """Parameter container for one down / mid / up stage (resnets, attentions, downsample / upsample)."""
+
+
+class UNet(_HipModule):
+    def __init__(self, num_attention_heads: int = 8, block_out_channels: List[int] = [320, 640, 1280, 1280],
+                 cross_attention_dim: int = 768, in_channels: int = 4, layers_per_block: int = 2,
+                 transformer_layers_per_block: int = 1, norm_num_groups: float = 32, dropout: float = 0.0,
+                 feed_forward_mult: int = 4, activation_fn: str = "geglu"):
+        super().__init__()
+        assert len(block_out_channels) > 1  # unet.py:24
+        ch = list(block_out_channels)
+        self.block_out_channels = block_out_channels
+        self.norm_num_groups = g = int(norm_num_groups)
+        temb = ch[0] * 4
+        n = len(ch)
+
+        def res(cin, cout):
+            return ResnetBlock(cin, cout, temb, g, dropout)
+
+        def tf(c):
+            return TransformerModel(c, num_attention_heads, transformer_layers_per_block, cross_attention_dim, dropout, g,
+                                    feed_forward_mult, activation_fn)
+
+        self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
+        self.conv_in._ldm_raw = True
+        self.time_embedding = _seq(nn.Linear(ch[0], temb), nn.Identity(), nn.Linear(temb, temb))
+        downs = []
+        for i in range(n):
+            cin = ch[0] if i == 0 else ch[i - 1]
+            blk = _Stage()
+            blk.resnets = nn.ModuleList([res(cin if j == 0 else ch[i], ch[i]) for j in range(layers_per_block)])
+            if i < n - 1:  # the last down stage has neither attention nor a downsampler (unet.py:38-46)
+                blk.attentions = nn.ModuleList([tf(ch[i]) for _ in range(layers_per_block)])
+                blk.downsample = nn.Conv2d(ch[i], ch[i], 3, stride=2, padding=1)
+            downs.append(blk)
+        self.down_blocks = nn.ModuleList(downs)
+        mid = _Stage()
+        mid.resnets = nn.ModuleList([res(ch[-1], ch[-1]) for _ in range(2)])
+        mid.attentions = nn.ModuleList([tf(ch[-1])])
+        self.mid_block = mid
+        ups = []
+        for i in range(n):
+            rev = n - 1 - i
+            cin = ch[-1] if i == 0 else ch[rev + 1]
+            cout = ch[rev]
+            last_skip = ch[0] if rev == 0 else ch[rev - 1]
+            L = layers_per_block + 1
+            blk = _Stage()
+            blk.resnets = nn.ModuleList([res((cin if j == 0 else cout) + (last_skip if j == L - 1 else cout), cout)
+                                         for j in range(L)])
+            if i > 0:
+                blk.attentions = nn.ModuleList([tf(cout) for _ in range(L)])
+            if i < n - 1:
+                blk.upsample = nn.Conv2d(cout, cout, 3, padding=1)
+            ups.append(blk)
+        self.up_blocks = nn.ModuleList(ups)
+        self.final_conv = _seq(nn.GroupNorm(g, ch[0]), nn.Identity(), nn.Conv2d(ch[0], in_channels, 3, padding=1))
+        self.final_conv[2]._ldm_raw = True
+        for m in self.modules():  # the per-block time projections run as one fused GEMM
+            if isinstance(m, ResnetBlock):
+                m.time[1]._ldm_skip = True
+
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                encoder_hidden_states: torch.Tensor) -> torch.Tensor:
+        self._check_call(sample)
+        dt = compute_dtype_of(sample)
+        P = self._packed_for(dt)
+        B = sample.shape[0]
+        dev = sample.device
+
+        # timestep forms of unet.py:159-170 (python int -> int64, float -> float64, 0-d tensor, (B,) tensor)
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64)
+        elif t.dim() == 0:
+            t = t[None]
+        t = t.to(dev, non_blocking=True).expand(B).to(torch.float32)
+
+        emb = ops.timestep_embedding(t, self.block_out_channels[0], dt)
+        e = ops.conv_gemm(emb, P["time_embedding.0.w"], bias=P["time_embedding.0.b"], silu=True)
+        e = ops.conv_gemm(e, P["time_embedding.2.w"], bias=P["time_embedding.2.b"], silu=True)  # SiLU of ResnetBlock.time
+        tproj = ops.conv_gemm(e, P["time_all.w"], bias=P["time_all.b"])
+
+        def resnet(name, r, x, skip):
+            off = P[name + ".time_off"]
+            return run_resnet(P, name, r, x, skip, tproj[:, off:off + r.out_channels])
+
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        h = ops.conv_in(sample.contiguous(), P["conv_in.w"], P["conv_in.b"], dt)
+        skips = [h]
+        for i, blk in enumerate(self.down_blocks):
+            attns = getattr(blk, "attentions", None)
+            for j, r in enumerate(blk.resnets):
+                h = resnet(f"down_blocks.{i}.resnets.{j}", r, h, None)
+                if attns is not None:
+                    h = run_transformer_model(P, f"down_blocks.{i}.attentions.{j}", attns[j], h, ctx)
+                skips.append(h)
+            if hasattr(blk, "downsample"):
+                nm = f"down_blocks.{i}.downsample"
+                h = ops.conv_gemm(h, P[nm + ".w"], ksize=3, stride=2, bias=P[nm + ".b"])
+                skips.append(h)
+        mid = self.mid_block
+        h = resnet("mid_block.resnets.0", mid.resnets[0], h, None)
+        h = run_transformer_model(P, "mid_block.attentions.0", mid.attentions[0], h, ctx)
+        h = resnet("mid_block.resnets.1", mid.resnets[1], h, None)
+        for i, blk in enumerate(self.up_blocks):
+            attns = getattr(blk, "attentions", None)
+            for j, r in enumerate(blk.resnets):
+                h = resnet(f"up_blocks.{i}.resnets.{j}", r, h, skips.pop())
+                if attns is not None:
+                    h = run_transformer_model(P, f"up_blocks.{i}.attentions.{j}", attns[j], h, ctx)
+            if hasattr(blk, "upsample"):
+                nm = f"up_blocks.{i}.upsample"
+                h = ops.conv_gemm(h, P[nm + ".w"], ksize=3, upsample=True, bias=P[nm + ".b"])
+        h = ops.groupnorm(h, P["final_conv.0.g"], P["final_conv.0.b"], self.norm_num_groups, silu=True)
+        return ops.conv_out(h, P["final_conv.2.w"], P["final_conv.2.b"], dt)
