@@ -135,6 +135,10 @@ typedef struct LdmConvGemm {
  * GEGLU (:787-790), feed_forward (:579), down/upsample (:218,:317), time_embedding (:29-33). */
 int ldm_conv_gemm(const LdmConvGemm* desc, void* stream);
 
+/* The (BM, BN, BK) tile ldm_conv_gemm would pick for this descriptor (host-only query; used by bench.py to
+ * attribute measured launch times to kernel instantiations).  No counterpart in the reference. */
+int ldm_conv_gemm_tile(const LdmConvGemm* desc, int tile[3]);
+
 /* --------------------------------------------------------------------------- UNet: normalisation */
 
 /* Per-(sample, group) mean and rstd over an NHWC tensor (two-source virtual concat allowed).

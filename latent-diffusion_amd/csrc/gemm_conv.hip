@@ -401,6 +401,26 @@ static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per
   return useful * fill * size_bonus;
 }
 
+// Tile choice of the bf16 path: BK = 64 when no K-tile straddles a tap or a concat boundary, else 32;
+// among the BK = 64 tiles the one with the best (padding waste x chip fill) score; GLU epilogues need an even
+// number of 16-column tiles per wave, i.e. BN = 128.
+static void pick_tile_bf16(const ConvGemmParams& p, bool glu, int& bm, int& bn, int& bk) {
+  const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
+  if (!bk64) {
+    bk = 32;
+    if (p.M <= 64 * 256 && !glu) { bm = 64; bn = 64; } else { bm = 128; bn = 128; }
+    return;
+  }
+  bk = 64;
+  const double s_128_128 = tile_score(p, 128, 128, 2), s_64_128 = tile_score(p, 64, 128, 3);
+  if (glu) { bn = 128; bm = s_128_128 >= s_64_128 ? 128 : 64; return; }
+  const double s_128_160 = tile_score(p, 128, 160, 2), s_64_160 = tile_score(p, 64, 160, 3);
+  double best = s_128_128; bm = 128; bn = 128;
+  if (s_128_160 > best) { best = s_128_160; bm = 128; bn = 160; }
+  if (s_64_128 > best) { best = s_64_128; bm = 64; bn = 128; }
+  if (s_64_160 > best) { best = s_64_160; bm = 64; bn = 160; }
+}
+
 }  // namespace ldm
 
 using namespace ldm;
@@ -456,26 +476,29 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
 
   LDM_REQUIRE(p.ctot % 32 == 0 && p.c0 % 32 == 0, "ldm_conv_gemm(bf16): channel counts must be multiples of 32 (c0=%d c1=%d)", d->c0, d->c1);
   LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
-  const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
-  if (!bk64) {
-    if (p.M <= 64 * 256 && !glu) return launch_bf16<64, 64, 32, 2, 2>(p, st);
-    return launch_bf16<128, 128, 32, 2, 2>(p, st);
+  int bm, bn, bk;
+  pick_tile_bf16(p, glu, bm, bn, bk);
+  const int key = bm * 1000000 + bn * 1000 + bk;
+  switch (key) {
+    case 64064032: return launch_bf16<64, 64, 32, 2, 2>(p, st);
+    case 128128032: return launch_bf16<128, 128, 32, 2, 2>(p, st);
+    case 128128064: return launch_bf16<128, 128, 64, 2, 2>(p, st);
+    case 64128064: return launch_bf16<64, 128, 64, 2, 2>(p, st);
+    case 128160064: return launch_bf16<128, 160, 64, 2, 2>(p, st);
+    case 64160064: return launch_bf16<64, 160, 64, 2, 2>(p, st);
+    default: break;
   }
-  // candidates (BM, BN, blocks/CU): GLU needs an even number of 16-column tiles per wave -> BN = 128
-  double s_128_128 = tile_score(p, 128, 128, 2);
-  double s_64_128 = tile_score(p, 64, 128, 3);
-  if (glu) return s_128_128 >= s_64_128 ? launch_bf16<128, 128, 64, 2, 2>(p, st) : launch_bf16<64, 128, 64, 2, 2>(p, st);
-  double s_128_160 = tile_score(p, 128, 160, 2);
-  double s_64_160 = tile_score(p, 64, 160, 3);
-  double best = s_128_128;
-  int pick = 0;
-  if (s_128_160 > best) { best = s_128_160; pick = 1; }
-  if (s_64_128 > best) { best = s_64_128; pick = 2; }
-  if (s_64_160 > best) { best = s_64_160; pick = 3; }
-  switch (pick) {
-    case 1: return launch_bf16<128, 160, 64, 2, 2>(p, st);
-    case 2: return launch_bf16<64, 128, 64, 2, 2>(p, st);
-    case 3: return launch_bf16<64, 160, 64, 2, 2>(p, st);
-    default: return launch_bf16<128, 128, 64, 2, 2>(p, st);
-  }
+  set_error("ldm_conv_gemm: no kernel for tile %dx%dx%d", bm, bn, bk);
+  return LDM_EUNSUPPORTED;
+}
+
+extern "C" int ldm_conv_gemm_tile(const LdmConvGemm* d, int tile[3]) {
+  LDM_REQUIRE(d && tile, "ldm_conv_gemm_tile: null pointer");
+  if (d->dtype == LDM_F32) { tile[0] = 64; tile[1] = 64; tile[2] = 16; return LDM_OK; }
+  ConvGemmParams p;
+  p.c0 = d->c0; p.c1 = d->c1; p.ctot = d->c0 + d->c1;
+  p.M = d->batch * d->hout * d->wout; p.N = d->n;
+  const bool glu = (d->epilogue & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
+  pick_tile_bf16(p, glu, tile[0], tile[1], tile[2]);
+  return LDM_OK;
 }

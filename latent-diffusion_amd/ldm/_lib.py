@@ -8,6 +8,13 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the library is dlopen'ed: the PyTorch-ROCm wheel ships its own HIP runtime
+# (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7) and the kernels must run in that runtime, because the device
+# pointers and streams they are given are torch's.  Loaded first, torch's copy satisfies this library's
+# DT_NEEDED by SONAME; loaded second, a second runtime (/opt/rocm) would come up beside it and every launch
+# would fail with "no ROCm-capable device is detected".
+import torch  # noqa: F401
+
 F32, BF16 = 0, 1
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU, EPI_GEGLU, EPI_SWIGLU = 1, 2, 4, 8, 16, 32
@@ -51,6 +58,7 @@ _SIGNATURES = {
                            c_i64, c_void_p],
     "ldm_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ldm_conv_gemm": [C.POINTER(ConvGemmDesc), c_void_p],
+    "ldm_conv_gemm_tile": [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int)],
     "ldm_groupnorm_workspace_floats": [c_int, c_int],
     "ldm_groupnorm_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                             c_void_p, c_void_p],

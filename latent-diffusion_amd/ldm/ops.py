@@ -113,8 +113,28 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
                      bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
                      residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
     with torch.cuda.device(a0.device):
-        _lib.check(_lib.load().ldm_conv_gemm(C.byref(d), _stream(a0)), "ldm_conv_gemm")
+        if _launch_log is None:
+            _lib.check(_lib.load().ldm_conv_gemm(C.byref(d), _stream(a0)), "ldm_conv_gemm")
+        else:  # bench.py: bracket the launch with HIP events on the stream it runs on
+            tile = (C.c_int * 3)()
+            _lib.check(_lib.load().ldm_conv_gemm_tile(C.byref(d), tile), "ldm_conv_gemm_tile")
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(_lib.load().ldm_conv_gemm(C.byref(d), _stream(a0)), "ldm_conv_gemm")
+            e1.record()
+            m = batch * hout * wout
+            _launch_log.append((f"conv_gemm_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel<{tile[0]},{tile[1]},{tile[2]}>",
+                                2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1))
     return out
+
+
+_launch_log = None
+
+
+def set_launch_log(log):
+    """bench.py hook: a list that receives (kernel name, algorithmic FLOPs, start event, end event) per GEMM launch."""
+    global _launch_log
+    _launch_log = log
 
 
 _gn_ws = {}
