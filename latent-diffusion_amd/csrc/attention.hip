@@ -45,8 +45,10 @@ struct AttnGeom {
   static constexpr int NCH = (64 * CPR + 255) / 256;   // chunks per thread per tile and operand
 };
 
+// D <= 80: two waves per SIMD (<= 256 registers), which also makes hipcc keep the MFMA accumulators in VGPRs
+// (with 512 registers allowed it parks them in AGPRs and pays ~200 v_accvgpr moves per key tile for the rescale).
 template <int D>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
 attention_bf16_kernel(const AttnParams p) {
   using G = AttnGeom<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -160,7 +162,7 @@ attention_bf16_kernel(const AttnParams p) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[g], mx * p.scale_log2e);
-      const float alpha = exp2f(m_run[g] - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
       m_run[g] = m_new;
       float psum = 0.f;
       float pv[4][4];
@@ -168,7 +170,7 @@ attention_bf16_kernel(const AttnParams p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[g][kb][r] * p.scale_log2e - m_new);
+          const float e = __builtin_amdgcn_exp2f(s[g][kb][r] * p.scale_log2e - m_new);  // raw v_exp_f32: arguments <= 0
           pv[kb][r] = e;
           psum += e;
         }

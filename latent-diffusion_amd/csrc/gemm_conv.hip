@@ -35,6 +35,7 @@ struct ConvGemmParams {
   void* out;
   int out_f32;      // out dtype is float32 (else same as compute dtype)
   int tiles_m, tiles_n;
+  int vec_epilogue; // 16-byte epilogue accesses are legal (alignment and n % 8 checked on the host)
 };
 
 template <int CH>
@@ -190,6 +191,85 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int nout = glu ? p.N >> 1 : p.N;
   const bf16_t* resid = static_cast<const bf16_t*>(p.residual);
   const bf16_t* rowv = static_cast<const bf16_t*>(p.rowvec);
+  if (p.vec_epilogue) {
+    // Vector epilogue: each wave transposes its accumulators through LDS, 16 rows at a time, so that a lane owns 8
+    // consecutive output columns: bias / time-embedding / residual operands and the result move as 16-byte accesses
+    // (the scalar form below issues one 2-byte store per accumulator register and is store-issue bound at small K).
+    constexpr int LDC = WTN + 4;                                  // floats per staged row (+4: spreads the 4 row groups)
+    static_assert(WM * WN * 16 * LDC * 4 <= 2 * STAGE, "epilogue staging does not fit the tile buffers");
+    float* cst = reinterpret_cast<float*>(smem) + wave * (16 * LDC);
+    constexpr int WOUT = WTN;                                     // staged columns per wave
+    const int cprw = glu ? WOUT / 16 : WOUT / 8;                  // 8-column output chunks per staged row
+    const int ncol0 = n0 + wn * WTN;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cst[(fq * 4 + r) * LDC + j * 16 + fr] = acc[i][j][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int c = lane; c < 16 * cprw; c += 64) {
+        const int row = c / cprw, cc = c - row * cprw;
+        const int m = m0 + wm * WTM + i * 16 + row;
+        float v[8];
+        int ncol, ocol;                                           // first filter row / first output column of the chunk
+        if (!glu) {
+          ncol = ncol0 + cc * 8;
+          ocol = ncol;
+          const float4 x0 = *reinterpret_cast<const float4*>(cst + row * LDC + cc * 8);
+          const float4 x1 = *reinterpret_cast<const float4*>(cst + row * LDC + cc * 8 + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+        } else {
+          const int sc = (cc >> 1) * 32 + (cc & 1) * 8;           // value columns; gates sit 16 further
+          ncol = ncol0 + sc;
+          ocol = (ncol0 >> 1) + cc * 8;
+          float g[8], b[8], bg[8];
+          const float4 x0 = *reinterpret_cast<const float4*>(cst + row * LDC + sc);
+          const float4 x1 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 4);
+          const float4 g0 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 16);
+          const float4 g1 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 20);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
+          if (m < p.M && ncol < p.N) {
+            if (epi & LDM_EPI_BIAS) {
+              load8(p.bias + ncol, b);
+              load8(p.bias + ncol + 16, bg);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { v[e] += b[e]; g[e] += bg[e]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= (epi & LDM_EPI_GEGLU) ? gelu_erf_f(g[e]) : silu_f(g[e]);
+          }
+        }
+        if (m >= p.M || ncol >= p.N) continue;
+        if (!glu) {
+          float t[8];
+          if (epi & LDM_EPI_BIAS) {
+            load8(p.bias + ncol, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+          if (epi & LDM_EPI_ROWVEC) {
+            load8(rowv + (size_t)(m / hw_out) * p.rowvec_stride + ncol, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+          if (epi & LDM_EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+          }
+          if (epi & LDM_EPI_RESIDUAL) {
+            load8(resid + (size_t)m * p.N + ncol, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e];
+          }
+        }
+        if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * nout + ocol, v);
+        else store8(static_cast<bf16_t*>(p.out) + (size_t)m * nout + ocol, v);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -461,6 +541,7 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.epilogue = epi; p.bias = d->bias; p.rowvec = d->rowvec; p.rowvec_stride = d->rowvec_stride;
   p.residual = d->residual; p.out = d->out;
   p.out_f32 = d->out_dtype == LDM_F32;
+  p.vec_epilogue = 0;
   hipStream_t st = (hipStream_t)stream;
 
   if (d->dtype == LDM_F32) {
@@ -476,6 +557,16 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
 
   LDM_REQUIRE(p.ctot % 32 == 0 && p.c0 % 32 == 0, "ldm_conv_gemm(bf16): channel counts must be multiples of 32 (c0=%d c1=%d)", d->c0, d->c1);
   LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
+  {
+    const int nout = glu ? p.N / 2 : p.N;
+    const size_t osz = p.out_f32 ? 4 : 2;
+    bool ok = p.N % 8 == 0 && nout % 8 == 0 && aligned16(p.out) && ((size_t)nout * osz) % 16 == 0;
+    if (epi & LDM_EPI_BIAS) ok = ok && aligned16(p.bias);
+    if (epi & LDM_EPI_ROWVEC) ok = ok && aligned16(p.rowvec) && p.rowvec_stride % 8 == 0;
+    if (epi & LDM_EPI_RESIDUAL) ok = ok && aligned16(p.residual);
+    if (glu) ok = ok && p.N % 32 == 0;
+    p.vec_epilogue = ok ? 1 : 0;
+  }
   int bm, bn, bk;
   pick_tile_bf16(p, glu, bm, bn, bk);
   const int key = bm * 1000000 + bn * 1000 + bk;

@@ -39,39 +39,50 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int batch
   Elem<T>::st(out + i, c < half ? cosf(arg) : sinf(arg));  // flip_sin_to_cos: cosine half first
 }
 
-// conv_in: NCHW (few channels) -> NHWC, one thread per (pixel, 8 output channels)
+// conv_in: NCHW (few channels) -> NHWC, one thread per (pixel, 8 output channels).  The filter is staged once per
+// block in LDS as [tap][cout] so that neighbouring threads (neighbouring channel chunks) read neighbouring words.
 template <typename TX, typename TO, int CIN>
 __global__ void __launch_bounds__(256)
 conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
                int batch, int h, int wd, int cout) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [CIN*9][cout]
+  constexpr int TAPS = CIN * 9;
+  for (int i = threadIdx.x; i < TAPS * cout; i += 256) {
+    const int co = i / TAPS, tap = i - co * TAPS;   // w is [cout][CIN][3][3]
+    wl[tap * cout + co] = w[i];
+  }
+  __syncthreads();
   const int chunks = cout >> 3;
   const int64_t total = (int64_t)batch * h * wd * chunks;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int ch = (int)(i % chunks);
-  const int64_t pix = i / chunks;
-  const int ow = (int)(pix % wd);
-  const int oh = (int)((pix / wd) % h);
-  const int b = (int)(pix / ((int64_t)wd * h));
-  float acc[8];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ch = (int)(i % chunks);
+    const int64_t pix = i / chunks;
+    const int ow = (int)(pix % wd);
+    const int oh = (int)((pix / wd) % h);
+    const int b = (int)(pix / ((int64_t)wd * h));
+    float acc[8];
+    load8(bias + ch * 8, acc);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = bias[ch * 8 + j];
+    for (int ci = 0; ci < CIN; ++ci) {
 #pragma unroll
-  for (int ci = 0; ci < CIN; ++ci) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      const int ih = oh + kh - 1;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow + kw - 1;
+          float v = 0.f;
+          if (ih >= 0 && ih < h && iw >= 0 && iw < wd) v = Elem<TX>::ld(x + (((int64_t)b * CIN + ci) * h + ih) * wd + iw);
+          float wv[8];
+          load8(wl + ((ci * 3 + kh) * 3 + kw) * cout + ch * 8, wv);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int iw = ow + kw - 1;
-        float v = 0.f;
-        if (ih >= 0 && ih < h && iw >= 0 && iw < wd) v = Elem<TX>::ld(x + (((int64_t)b * CIN + ci) * h + ih) * wd + iw);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v * w[(((ch * 8 + j) * CIN + ci) * 3 + kh) * 3 + kw];
+          for (int j = 0; j < 8; ++j) acc[j] += v * wv[j];
+        }
       }
     }
+    store8(out + pix * cout + ch * 8, acc);
   }
-  store8(out + pix * cout + ch * 8, acc);
 }
 
 // generic channel count (slow path)
@@ -187,9 +198,11 @@ template <typename TX, typename TO>
 static int conv_in_dispatch(const void* x, const float* w, const float* bias, void* out, int batch, int cin, int h,
                             int wd, int cout, hipStream_t st) {
   const int64_t npix = (int64_t)batch * h * wd;
-  if (cin == 4 && cout % 8 == 0 && aligned16(out)) {
-    hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3(blocks_for(npix * (cout / 8))), dim3(256), 0, st, (const TX*)x, w, bias,
-                       (TO*)out, batch, h, wd, cout);
+  if (cin == 4 && cout % 8 == 0 && cout <= 448 && aligned16(out) && aligned16(bias)) {
+    int64_t nb = (npix * (cout / 8) + 255) / 256;
+    if (nb > 2048) nb = 2048;  // grid-stride: the LDS filter image is filled once per block
+    hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3((int)nb), dim3(256), (size_t)36 * cout * sizeof(float), st, (const TX*)x,
+                       w, bias, (TO*)out, batch, h, wd, cout);
   } else {
     hipLaunchKernelGGL((conv_in_generic_kernel<TX, TO>), dim3(blocks_for(npix * cout)), dim3(256), 0, st, (const TX*)x, w, bias,
                        (TO*)out, batch, cin, h, wd, cout);

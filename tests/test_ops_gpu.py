@@ -58,7 +58,7 @@ def test_pack_weight_layouts():
 # ------------------------------------------------------------------------------------- conv_gemm
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (128, 128, 64), (1000, 640, 768), (77, 1280, 768), (33, 64, 32),
-                                   (4100, 160, 96), (256, 2560, 320)])
+                                   (4100, 160, 96), (256, 2560, 320), (50, 20, 64), (130, 328, 128)])
 def test_linear_bias(dtype, M, N, K):
     ops = _ops()
     x, xr = _q(seeded((M, K), 1), dtype)

@@ -1,0 +1,65 @@
+"""Micro-benchmark of the implicit-GEMM kernel on the UNet's characteristic shapes (B=32, 64x64 latents).
+Usage: python tools/gemm_bench.py [case-substring] [--iters N]"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "latent-diffusion_amd"))
+from ldm import ops  # noqa: E402
+
+B = 32
+CASES = [  # name, (H, W, C0, C1), N, ksize, stride, up, glu
+    ("L0 conv3x3 320->320", (64, 64, 320, 0), 320, 3, 1, False, None),
+    ("L0 conv3x3 960->320 cat", (64, 64, 640, 320), 320, 3, 1, False, None),
+    ("L1 conv3x3 640->640", (32, 32, 640, 0), 640, 3, 1, False, None),
+    ("L2 conv3x3 1280->1280", (16, 16, 1280, 0), 1280, 3, 1, False, None),
+    ("L3 conv3x3 1280->1280", (8, 8, 1280, 0), 1280, 3, 1, False, None),
+    ("L3 conv3x3 2560->1280 cat", (8, 8, 1280, 1280), 1280, 3, 1, False, None),
+    ("L0 down s2 320->320", (64, 64, 320, 0), 320, 3, 2, False, None),
+    ("L0 up conv 640->640", (32, 32, 640, 0), 640, 3, 1, True, None),
+    ("L0 qkv 320->960", (64, 64, 320, 0), 960, 1, 1, False, None),
+    ("L0 geglu 320->2560", (64, 64, 320, 0), 2560, 1, 1, False, "geglu"),
+    ("L0 ffout 1280->320", (64, 64, 1280, 0), 320, 1, 1, False, None),
+    ("L0 proj 320->320", (64, 64, 320, 0), 320, 1, 1, False, None),
+    ("L1 geglu 640->5120", (32, 32, 640, 0), 5120, 1, 1, False, "geglu"),
+    ("L2 geglu 1280->10240", (16, 16, 1280, 0), 10240, 1, 1, False, "geglu"),
+    ("ctx kv 768->640", (77, 1, 768, 0), 640, 1, 1, False, None),
+]
+
+
+def main():
+    sel = [a for a in sys.argv[1:] if not a.startswith("--")]
+    iters = 20
+    if "--iters" in sys.argv:
+        iters = int(sys.argv[sys.argv.index("--iters") + 1])
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(0)
+    for name, (H, W, c0, c1), N, ks, stride, up, glu in CASES:
+        if sel and not any(s in name for s in sel):
+            continue
+        a0 = torch.randn(B, H, W, c0, device=dev, generator=g).bfloat16()
+        a1 = torch.randn(B, H, W, c1, device=dev, generator=g).bfloat16() if c1 else None
+        K = ks * ks * (c0 + c1)
+        w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
+        bias = torch.randn(N, device=dev, generator=g)
+        kw = dict(a1=a1, ksize=ks, stride=stride, upsample=up, bias=bias, glu=glu)
+        out = ops.conv_gemm(a0, w, **kw)
+        M = out.numel() // out.shape[-1]
+        for _ in range(3):
+            ops.conv_gemm(a0, w, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ops.conv_gemm(a0, w, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        fl = 2.0 * M * N * K
+        print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
