@@ -59,16 +59,25 @@ __device__ __forceinline__ void epilogue_store(const ConvGemmParams& p, int m, i
   // generic scalar epilogue element (bias / rowvec / residual / silu), n < N and m < M guaranteed by caller
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ void __launch_bounds__(64 * WM * WN)
+// 16 bytes per lane from a raw buffer (base, bytes) straight into LDS: `buffer_load_dwordx4 v, s[rsrc], s offen lds`.
+// voff is the per-lane byte offset, soff a wave-uniform one; an offset past `bytes` makes the hardware write zeros.
+// (Kept in a __device__ function: the resource type does not exist in the host pass that emits the kernel stub.)
+__device__ __forceinline__ void dma16_to_lds(const void* base, unsigned bytes, unsigned char* lds, unsigned voff, int soff) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES>
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 1))
 conv_gemm_bf16_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
   constexpr int ROWB = BK * 2;               // bytes per tile row
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int A_IT = BM * CH / NT, B_IT = BN * CH / NT;
-  static_assert(BM * CH % NT == 0 && BN * CH % NT == 0, "tile/threads mismatch");
+  constexpr int A_IT = BM * CH / NT, B_IT = (BN * CH + NT - 1) / NT;
+  constexpr int B_FULL = BN * CH / NT;       // B staging passes every wave takes part in
+  static_assert(BM * CH % NT == 0 && (BN * CH) % 64 == 0, "tile/threads mismatch");
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int MI = WTM / 16, NI = WTN / 16, KS = BK / 32;
   static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
@@ -84,12 +93,16 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-  const bf16_t* a0 = static_cast<const bf16_t*>(p.a0);
-  const bf16_t* a1 = static_cast<const bf16_t*>(p.a1);
-  const bf16_t* wq = static_cast<const bf16_t*>(p.w);
+  // ---- operand staging: LDS-DMA through buffer descriptors.  Per K-tile a wave issues A_IT + B_IT
+  // `buffer_load_dwordx4 ... offen lds` with a per-lane byte offset that stays fixed while the K loop walks the
+  // channels of one (tap, source) and a SCALAR offset that advances by one K-tile: no vector ALU work per tile.
+  // Padding taps, rows past M and filter rows past N carry an out-of-range offset: the descriptor's range check
+  // makes the hardware write zeros to LDS for them.
+  constexpr unsigned OOB = 0x80000000u;      // every buffer here is < 2 GiB (checked on the host)
+  const unsigned bytes_a0 = (unsigned)p.batch * p.hin * p.win * p.c0 * 2u;
+  const unsigned bytes_a1 = (unsigned)p.batch * p.hin * p.win * (p.c1 ? p.c1 : p.c0) * 2u;
+  const unsigned bytes_w = (unsigned)p.N * p.K * 2u;
 
-  // ---- per-thread staging coordinates (fixed over the K loop)
   const int cpos = tid % CH;                 // chunk position inside the LDS row this thread fills
   int a_pix[A_IT], a_ih[A_IT], a_iw[A_IT], a_sw[A_IT];
   const int hw_out = p.hout * p.wout;
@@ -112,37 +125,57 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       a_ih[it] = a_iw[it] = 0;
     }
   }
-  const bf16_t* b_src[B_IT];
+  unsigned b_voff[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    const int r = (it * NT + tid) / CH;
+    const int r = (it * NT + tid) / CH;      // may run past BN in the last, partial pass (never staged then)
     const int n = n0 + r;
-    b_src[it] = n < p.N ? wq + (size_t)n * p.K + (cpos ^ swz<CH>(r)) * 8 : nullptr;
+    b_voff[it] = n < p.N ? ((unsigned)n * p.K + (cpos ^ swz<CH>(r)) * 8) * 2u : OOB;
   }
 
+  // K-loop iterator (block-uniform): tap -> source -> channel offset inside the source
+  int it_tap = 0, it_second = 0, it_cc = 0;
+  bool it_fresh = true;
+  unsigned a_voff[A_IT];
   auto stage = [&](int buf, int kt) {
     unsigned char* sa = smem + buf * STAGE;
     unsigned char* sb = sa + A_BYTES;
-    const int k0 = kt * BK;
-    const int tap = k0 / p.ctot;             // block-uniform: ctot % BK == 0
-    const int c = k0 - tap * p.ctot;
-    const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
-    const bool second = c >= p.c0;           // c0 % BK == 0
-    const bf16_t* src = second ? a1 : a0;
-    const int cs = second ? p.c1 : p.c0;
-    const int cc = second ? c - p.c0 : c;
+    const int cs = it_second ? p.c1 : p.c0;
+    if (it_fresh) {                          // new (tap, source): per-lane offsets change
+      const int kh = it_tap / p.ksize, kw = it_tap - kh * p.ksize;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
-      const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
-      if (p.upsample) { ih >>= 1; iw >>= 1; }
-      const bf16_t* g = ok ? src + ((size_t)(a_pix[it] + ih * p.win + iw) * cs + cc + a_sw[it]) : zero;
-      glds16(g, sa + (it * NT + wave * 64) * 16);
+      for (int it = 0; it < A_IT; ++it) {
+        int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
+        const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+        if (p.upsample) { ih >>= 1; iw >>= 1; }
+        a_voff[it] = ok ? ((unsigned)(a_pix[it] + ih * p.win + iw) * cs + a_sw[it]) * 2u : OOB;
+      }
+      it_fresh = false;
     }
+    const int soff_a = it_cc * 2;
+    if (it_second) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        dma16_to_lds(p.a1, bytes_a1, sa + (it * NT + wave * 64) * 16, a_voff[it], soff_a);
+    } else {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        dma16_to_lds(p.a0, bytes_a0, sa + (it * NT + wave * 64) * 16, a_voff[it], soff_a);
+    }
+    const int soff_b = kt * (BK * 2);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const bf16_t* g = b_src[it] ? b_src[it] + k0 : zero;
-      glds16(g, sb + (it * NT + wave * 64) * 16);
+      if (it < B_FULL || (it * NT + wave * 64) < BN * CH) {   // wave-uniform
+        dma16_to_lds(p.w, bytes_w, sb + (it * NT + wave * 64) * 16, b_voff[it], soff_b);
+      }
+    }
+    // advance the iterator
+    it_cc += BK;
+    if (it_cc >= cs) {
+      it_cc = 0;
+      it_fresh = true;
+      if (!it_second && p.c1 > 0) it_second = 1;
+      else { it_second = 0; ++it_tap; }
     }
   };
 
@@ -155,13 +188,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int fr = lane & 15, fq = lane >> 4;
   const int nk = p.K / BK;
 
-  stage(0, 0);
-  __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const unsigned char* sa = smem + cur * STAGE;
+  auto compute = [&](int buf) {
+    const unsigned char* sa = smem + buf * STAGE;
     const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -182,7 +210,42 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+
+  if constexpr (STAGES == 2) {
+    stage(0, 0);
+    __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      compute(cur);
+      __syncthreads();
+    }
+  } else {
+    // 3-slot ring, ONE raw barrier per K-tile, the LDS-DMA of the tile after next stays in flight across it:
+    //   wait (counted) until this wave's loads of tile kt have landed -> barrier (now every wave's have, and every
+    //   wave is done reading tile kt-1) -> refill the slot of tile kt-1 with tile kt+2 -> math on tile kt.
+    // vmcnt counts this wave's LDS-DMA in issue order; a wave issues A_IT + B_FULL (+1 for the waves that take
+    // part in the partial last B pass) per tile.
+    static_assert(STAGES == 3, "ring depth");
+    const bool extra = B_IT > B_FULL && (B_FULL * NT + wave * 64) < BN * CH;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    int slot = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) {
+        if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_FULL + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_FULL) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+      compute(slot);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+    __syncthreads();  // tile buffers become the epilogue's staging area
   }
 
   // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
@@ -196,7 +259,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // consecutive output columns: bias / time-embedding / residual operands and the result move as 16-byte accesses
     // (the scalar form below issues one 2-byte store per accumulator register and is store-issue bound at small K).
     constexpr int LDC = WTN + 4;                                  // floats per staged row (+4: spreads the 4 row groups)
-    static_assert(WM * WN * 16 * LDC * 4 <= 2 * STAGE, "epilogue staging does not fit the tile buffers");
+    static_assert(WM * WN * 16 * LDC * 4 <= STAGES * STAGE, "epilogue staging does not fit the tile buffers");
     float* cst = reinterpret_cast<float*>(smem) + wave * (16 * LDC);
     constexpr int WOUT = WTN;                                     // staged columns per wave
     const int cprw = glu ? WOUT / 16 : WOUT / 8;                  // 8-column output chunks per staged row
@@ -453,12 +516,12 @@ conv_gemm_f32_kernel(const ConvGemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ launch
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2>
 static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  const int smem = 2 * (BM + BN) * BK * 2;
-  auto kern = conv_gemm_bf16_kernel<BM, BN, BK, WM, WN>;
+  const int smem = STAGES * (BM + BN) * BK * 2;
+  auto kern = conv_gemm_bf16_kernel<BM, BN, BK, WM, WN, STAGES>;
   static bool attr_done = false;  // opt in to > 64 KiB of dynamic LDS once per instantiation
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -477,7 +540,9 @@ static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per
   const double slots = 256.0 * blocks_per_cu;
   const double rounds = ceil(tiles / slots);
   const double fill = tiles / (rounds * slots);                            // tail / under-fill
-  const double size_bonus = (BM * BN >= 128 * 128) ? 1.0 : 0.85;           // small tiles: less operand reuse
+  // operand reuse: 128-row tiles > 64-row tiles.  The 256-row, 8-wave, 3-slot-ring tiles measured equal to the
+  // 128-row ones at best (profiles/r1_gemm_tile_sweep.txt), so they only win a tie-break on fill.
+  const double size_bonus = BM >= 256 ? 0.97 : ((BM * BN >= 128 * 128) ? 1.0 : 0.85);
   return useful * fill * size_bonus;
 }
 
@@ -492,13 +557,29 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, int& bm, int& bn, 
     return;
   }
   bk = 64;
+  if (const char* force = getenv("LDM_GEMM_TILE")) {   // tuning knob (tools/gemm_bench.py): "BM,BN" of a BK=64 tile
+    int fm = 0, fn = 0;
+    if (sscanf(force, "%d,%d", &fm, &fn) == 2 && (fm == 64 || fm == 128 || fm == 256) && (fn == 128 || (fn == 160 && !glu))) {
+      bm = fm; bn = fn;
+      return;
+    }
+  }
   const double s_128_128 = tile_score(p, 128, 128, 2), s_64_128 = tile_score(p, 64, 128, 3);
-  if (glu) { bn = 128; bm = s_128_128 >= s_64_128 ? 128 : 64; return; }
+  const double s_256_128 = tile_score(p, 256, 128, 1);
+  if (glu) {
+    bn = 128;
+    bm = s_128_128 >= s_64_128 ? 128 : 64;
+    if (s_256_128 > (bm == 128 ? s_128_128 : s_64_128)) bm = 256;
+    return;
+  }
   const double s_128_160 = tile_score(p, 128, 160, 2), s_64_160 = tile_score(p, 64, 160, 3);
   double best = s_128_128; bm = 128; bn = 128;
   if (s_128_160 > best) { best = s_128_160; bm = 128; bn = 160; }
   if (s_64_128 > best) { best = s_64_128; bm = 64; bn = 128; }
   if (s_64_160 > best) { best = s_64_160; bm = 64; bn = 160; }
+  const double s_256_160 = tile_score(p, 256, 160, 1);
+  if (s_256_128 > best) { best = s_256_128; bm = 256; bn = 128; }
+  if (s_256_160 > best) { best = s_256_160; bm = 256; bn = 160; }
 }
 
 }  // namespace ldm
@@ -556,6 +637,11 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   }
 
   LDM_REQUIRE(p.ctot % 32 == 0 && p.c0 % 32 == 0, "ldm_conv_gemm(bf16): channel counts must be multiples of 32 (c0=%d c1=%d)", d->c0, d->c1);
+  {
+    const long long pix = (long long)d->batch * d->hin * d->win;
+    LDM_REQUIRE(pix * d->c0 * 2 < (1LL << 31) && pix * d->c1 * 2 < (1LL << 31) && (long long)p.N * p.K * 2 < (1LL << 31),
+                "ldm_conv_gemm(bf16): an operand exceeds 2 GiB (32-bit buffer offsets)");
+  }
   LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
   {
     const int nout = glu ? p.N / 2 : p.N;
@@ -577,6 +663,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     case 64128064: return launch_bf16<64, 128, 64, 2, 2>(p, st);
     case 128160064: return launch_bf16<128, 160, 64, 2, 2>(p, st);
     case 64160064: return launch_bf16<64, 160, 64, 2, 2>(p, st);
+    case 256160064: return launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
+    case 256128064: return launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
     default: break;
   }
   set_error("ldm_conv_gemm: no kernel for tile %dx%dx%d", bm, bn, bk);

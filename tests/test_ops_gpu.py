@@ -155,6 +155,52 @@ def test_conv_two_sources(dtype, ksize):
     assert rel_l2(y, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("tile", ["64,128", "64,160", "128,128", "128,160", "256,128", "256,160"])
+def test_every_bf16_tile(tile, monkeypatch):
+    """Every BK=64 instantiation of the bf16 kernel (4-wave double-buffered and 8-wave 3-slot-ring), forced through the
+    LDM_GEMM_TILE tuning knob so coverage does not depend on the tile heuristic: linear + residual, GLU, 3x3 conv with
+    two sources + time embedding + ragged M, stride 2 and upsample."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    monkeypatch.setenv("LDM_GEMM_TILE", tile)
+    bm, bn = (int(v) for v in tile.split(","))
+    x, xr = _q(seeded((8200, 640), 1), dtype)
+    w = seeded((320, 640), 2) / math.sqrt(640)
+    b = seeded((320,), 3)
+    res, resr = _q(seeded((8200, 320), 4), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv_gemm(x, wp, bias=b.cuda(), residual=res)
+    assert rel_l2(y, F.linear(xr, wp.float().cpu(), b) + resr) < TOL[dtype]
+    wg = seeded((512, 640), 5) / math.sqrt(640)
+    bg = seeded((512,), 6)
+    y = ops.conv_gemm(x, ops.pack_weight(wg.cuda(), dtype, glu_pairs=True),
+                      bias=ops.pack_weight(bg.cuda(), torch.float32, glu_pairs=True).flatten(), glu="geglu")
+    val, gate = F.linear(xr, wg.to(dtype).float(), bg).chunk(2, dim=-1)
+    assert rel_l2(y, val * F.gelu(gate)) < TOL[dtype]
+    B, c0, c1, H, W, Cout = 9, 64, 64, 31, 30, 160
+    a, ar = _q(nhwc(seeded((B, c0, H, W), 7)), dtype)
+    s, sr = _q(nhwc(seeded((B, c1, H, W), 8)), dtype)
+    wc = seeded((Cout, c0 + c1, 3, 3), 9) / math.sqrt(9 * (c0 + c1))
+    bc = seeded((Cout,), 10)
+    rv, rvr = _q(seeded((B, Cout), 11), dtype)
+    y = ops.conv_gemm(a, ops.pack_weight(wc.cuda(), dtype), a1=s, ksize=3, bias=bc.cuda(), rowvec=rv)
+    cat = torch.cat([ar, sr], dim=-1).permute(0, 3, 1, 2)
+    ref = nhwc(F.conv2d(cat, wc.to(dtype).float(), bc, padding=1) + rvr[:, :, None, None])
+    assert rel_l2(y, ref) < TOL[dtype]
+    for stride, up in ((2, False), (1, True)):
+        xx, xxr = _q(nhwc(seeded((8, 64, 64, 64), 12)), dtype)
+        w3 = seeded((160, 64, 3, 3), 13) / math.sqrt(9 * 64)
+        y = ops.conv_gemm(xx, ops.pack_weight(w3.cuda(), dtype), ksize=3, stride=stride, upsample=up, bias=bc.cuda())
+        ref = nhwc(_conv_ref(xxr.permute(0, 3, 1, 2), w3.to(dtype).float(), bc, stride, up))
+        assert rel_l2(y, ref) < TOL[dtype]
+    import ctypes as C
+    from ldm import _lib
+    d = _lib.ConvGemmDesc(c0=640, c1=0, batch=8200, hin=1, win=1, hout=1, wout=1, ksize=1, stride=1, n=320, dtype=1, out_dtype=1)
+    t = (C.c_int * 3)()
+    _lib.check(_lib.load().ldm_conv_gemm_tile(C.byref(d), t))
+    assert list(t) == [bm, bn, 64], list(t)
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32

@@ -37,6 +37,9 @@ def main():
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(0)
+    tiles = [None]
+    if "--sweep" in sys.argv:   # every BK=64 tile the library instantiates, forced through LDM_GEMM_TILE
+        tiles = [None, "64,128", "64,160", "128,128", "128,160", "256,128", "256,160"]
     for name, (H, W, c0, c1), N, ks, stride, up, glu in CASES:
         if sel and not any(s in name for s in sel):
             continue
@@ -46,19 +49,28 @@ def main():
         w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
         bias = torch.randn(N, device=dev, generator=g)
         kw = dict(a1=a1, ksize=ks, stride=stride, upsample=up, bias=bias, glu=glu)
-        out = ops.conv_gemm(a0, w, **kw)
-        M = out.numel() // out.shape[-1]
-        for _ in range(3):
-            ops.conv_gemm(a0, w, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            ops.conv_gemm(a0, w, **kw)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
-        fl = 2.0 * M * N * K
-        print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d}  {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s", flush=True)
+        for tile in tiles:
+            if tile is None:
+                os.environ.pop("LDM_GEMM_TILE", None)
+            elif glu and tile.endswith("160"):
+                continue
+            else:
+                os.environ["LDM_GEMM_TILE"] = tile
+            out = ops.conv_gemm(a0, w, **kw)
+            M = out.numel() // out.shape[-1]
+            for _ in range(3):
+                ops.conv_gemm(a0, w, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                ops.conv_gemm(a0, w, **kw)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / iters
+            fl = 2.0 * M * N * K
+            print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d} tile={tile or 'auto':8s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s",
+                  flush=True)
+        os.environ.pop("LDM_GEMM_TILE", None)
 
 
 if __name__ == "__main__":
