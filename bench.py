@@ -153,7 +153,7 @@ def main():
         value = world * B * args.steps / elapsed
         # dominant kernel from the live event log
         per = {}
-        for name, flops, e0, e1 in log:
+        for name, flops, e0, e1, _shape in log:
             d = per.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += flops

@@ -35,17 +35,15 @@ typedef uint16_t bf16_t;  // raw storage
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (plain cast semantics of v_cvt_pk_bf16_f32)
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN: the hardware conversion (v_cvt_pk_bf16_f32), one instruction per pair
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw_t;
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_hw_t{lo, hi}, bf16x2_hw_t));
 }
+
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.0f) & 0xffffu); }
 
 template <typename T>
 struct Elem;
@@ -91,6 +89,25 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Epilogue forms for the bf16 path (results are rounded to bf16, 2^-9 relative): raw v_rcp_f32 / v_exp_f32, no
+// denormal or range fix-up code.
+//   silu_fast: exp2 overflow for x < -88 gives rcp(inf) = 0, i.e. the correct limit -0.
+//   gelu_erf_fast: 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7).
+//     For x < 0 it uses 1 + erf(-z) = erfc(z) = poly(t) exp(-z^2) directly, so the tail has no cancellation.
+__device__ __forceinline__ float silu_fast(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+}
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float q = fmaf(t, 1.061405429f, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float erfc_z = q * t * __builtin_amdgcn_exp2f(-1.44269504088896341f * z * z);
+  return 0.5f * x * (x >= 0.0f ? 2.0f - erfc_z : erfc_z);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

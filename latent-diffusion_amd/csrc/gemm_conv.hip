@@ -4,7 +4,7 @@
 //
 // A is never materialised: every 16-byte chunk of a K-tile is fetched straight from the NHWC activation
 // (one or two channel-concatenated sources, optional stride 2, optional nearest-2x upsample folded into the
-// index) into LDS by LDS-DMA (global_load_lds_dwordx4), padding taps read from a zero page.  W is packed
+// index) into LDS by LDS-DMA (buffer_load_dwordx4 ... lds), padding taps zero-filled by the buffer range check.  W is packed
 // [n][kh][kw][ci], so both MFMA operands are K-contiguous.  bf16 inputs, fp32 accumulation on
 // v_mfma_f32_16x16x32_bf16; the fp32 instantiation (exact fp32, v_mfma_f32_16x16x4_f32) serves the 1e-4 gate.
 //
@@ -12,12 +12,12 @@
 // the swizzle is applied to the per-lane SOURCE chunk and again on the fragment read (same involution).
 #include "common.h"
 
+#include <type_traits>
+
 namespace ldm {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-__device__ __align__(256) unsigned char g_zero_page[256];
 
 struct ConvGemmParams {
   const void* a0;
@@ -36,16 +36,26 @@ struct ConvGemmParams {
   int out_f32;      // out dtype is float32 (else same as compute dtype)
   int tiles_m, tiles_n;
   int vec_epilogue; // 16-byte epilogue accesses are legal (alignment and n % 8 checked on the host)
+#ifdef LDM_GEMM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only (make stamps): 8 cycle stamps per workgroup
+#endif
 };
+
+// Diagnostic build (make stamps -> libldm_amd_stamps.so, tools/gemm_stamps.py): thread 0 of every workgroup records
+// the shader clock at the phase boundaries of the bf16 kernel.  The product library compiles none of it.
+#ifdef LDM_GEMM_STAMPS
+#define LDM_STAMP(i)                                                                                      \
+  do {                                                                                                    \
+    if (p.stamps != nullptr && threadIdx.x == 0)                                                          \
+      p.stamps[(size_t)blockIdx.x * 8 + (i)] = (i) >= 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define LDM_STAMP(i) do {} while (0)
+#endif
 
 template <int CH>
 __device__ __forceinline__ int swz(int row) {
   return CH == 8 ? (row & 7) : ((row >> 1) & 3);
-}
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
 // bijective XCD remap: blocks b and b+8 share an XCD; give every XCD a contiguous run of tiles
@@ -54,9 +64,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <typename OutT>
-__device__ __forceinline__ void epilogue_store(const ConvGemmParams& p, int m, int n, float v) {
-  // generic scalar epilogue element (bias / rowvec / residual / silu), n < N and m < M guaranteed by caller
+// Raster order of the output tiles: bands of GROUP_M tile-rows, walked column by column.  The blocks in flight on
+// one XCD (a contiguous run of tile indices after xcd_remap) then cover a GROUP_M x ~8 patch: its A tiles and
+// filter tiles are fetched from HBM once and re-read from that XCD's L2, instead of streaming all of A once per
+// tile-column (at K = 320 and N = 2560 that was 20 passes over an 84 MB activation).
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_to_mn(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int band = GROUP_M * tiles_n;
+  const int g = tile / band, in = tile - g * band;
+  const int first = g * GROUP_M;
+  const int rows = min(tiles_m - first, GROUP_M);
+  tn = in / rows;
+  tm = first + (in - tn * rows);
 }
 
 // 16 bytes per lane from a raw buffer (base, bytes) straight into LDS: `buffer_load_dwordx4 v, s[rsrc], s offen lds`.
@@ -68,7 +87,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* base, unsigned bytes, u
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8 ? 2 : 1))
+__global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_gemm_bf16_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
@@ -83,6 +102,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   static_assert(WTM % 16 == 0 && WTN % 16 == 0, "wave tile must be a multiple of 16");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  LDM_STAMP(0);
+  LDM_STAMP(5);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -90,7 +111,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int wm = wave / WN, wn = wave % WN;
 
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  tile_to_mn(tile, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- operand staging: LDS-DMA through buffer descriptors.  Per K-tile a wave issues A_IT + B_IT
@@ -212,9 +234,11 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     }
   };
 
+  LDM_STAMP(1);
   if constexpr (STAGES == 2) {
     stage(0, 0);
     __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
+    LDM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
@@ -248,6 +272,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     __syncthreads();  // tile buffers become the epilogue's staging area
   }
 
+  LDM_STAMP(3);
   // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
   const int epi = p.epilogue;
   const bool glu = (epi & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
@@ -258,79 +283,117 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // Vector epilogue: each wave transposes its accumulators through LDS, 16 rows at a time, so that a lane owns 8
     // consecutive output columns: bias / time-embedding / residual operands and the result move as 16-byte accesses
     // (the scalar form below issues one 2-byte store per accumulator register and is store-issue bound at small K).
-    constexpr int LDC = WTN + 4;                                  // floats per staged row (+4: spreads the 4 row groups)
-    static_assert(WM * WN * 16 * LDC * 4 <= STAGES * STAGE, "epilogue staging does not fit the tile buffers");
-    float* cst = reinterpret_cast<float*>(smem) + wave * (16 * LDC);
-    constexpr int WOUT = WTN;                                     // staged columns per wave
-    const int cprw = glu ? WOUT / 16 : WOUT / 8;                  // 8-column output chunks per staged row
-    const int ncol0 = n0 + wn * WTN;
+    // The chunk geometry is compile-time, the bias is loaded once per lane, and the residual / time-embedding
+    // operands of 16-row step i+1 are requested before step i is transposed, so their L2 latency (the bulk of the
+    // epilogue when it was paid 3x per step) hides behind the LDS round trip and the stores of the step before.
+    auto run = [&](auto glu_tag) {
+      constexpr bool GLU = decltype(glu_tag)::value;
+      constexpr int LDC = WTN + 4;                                // floats per staged row (+4: spreads the 4 row groups)
+      static_assert(WM * WN * 16 * LDC * 4 <= STAGES * STAGE, "epilogue staging does not fit the tile buffers");
+      constexpr int CPRW = GLU ? WTN / 16 : WTN / 8;              // 8-column output chunks per staged row
+      constexpr int NCHUNK = 16 * CPRW;
+      constexpr int NPASS = (NCHUNK + 63) / 64;
+      float* cst = reinterpret_cast<float*>(smem) + wave * (16 * LDC);
+      const int ncol0 = n0 + wn * WTN;
+      const int mrow0 = m0 + wm * WTM;
+
+      int row[NPASS], scol[NPASS], ncol[NPASS], ocol[NPASS];
+      bool cok[NPASS];
+      float bv[NPASS][8], bg[GLU ? NPASS : 1][8];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int c = lane + 64 * ps;
+        row[ps] = c / CPRW;
+        const int cc = c - row[ps] * CPRW;
+        scol[ps] = GLU ? (cc >> 1) * 32 + (cc & 1) * 8 : cc * 8; // GLU: value columns; gates sit 16 further
+        ncol[ps] = ncol0 + scol[ps];
+        ocol[ps] = GLU ? (ncol0 >> 1) + cc * 8 : ncol[ps];
+        cok[ps] = c < NCHUNK && ncol[ps] < p.N;
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cst[(fq * 4 + r) * LDC + j * 16 + fr] = acc[i][j][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int c = lane; c < 16 * cprw; c += 64) {
-        const int row = c / cprw, cc = c - row * cprw;
-        const int m = m0 + wm * WTM + i * 16 + row;
-        float v[8];
-        int ncol, ocol;                                           // first filter row / first output column of the chunk
-        if (!glu) {
-          ncol = ncol0 + cc * 8;
-          ocol = ncol;
-          const float4 x0 = *reinterpret_cast<const float4*>(cst + row * LDC + cc * 8);
-          const float4 x1 = *reinterpret_cast<const float4*>(cst + row * LDC + cc * 8 + 4);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        } else {
-          const int sc = (cc >> 1) * 32 + (cc & 1) * 8;           // value columns; gates sit 16 further
-          ncol = ncol0 + sc;
-          ocol = (ncol0 >> 1) + cc * 8;
-          float g[8], b[8], bg[8];
-          const float4 x0 = *reinterpret_cast<const float4*>(cst + row * LDC + sc);
-          const float4 x1 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 4);
-          const float4 g0 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 16);
-          const float4 g1 = *reinterpret_cast<const float4*>(cst + row * LDC + sc + 20);
-          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          g[0] = g0.x; g[1] = g0.y; g[2] = g0.z; g[3] = g0.w; g[4] = g1.x; g[5] = g1.y; g[6] = g1.z; g[7] = g1.w;
-          if (m < p.M && ncol < p.N) {
-            if (epi & LDM_EPI_BIAS) {
-              load8(p.bias + ncol, b);
-              load8(p.bias + ncol + 16, bg);
-#pragma unroll
-              for (int e = 0; e < 8; ++e) { v[e] += b[e]; g[e] += bg[e]; }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= (epi & LDM_EPI_GEGLU) ? gelu_erf_f(g[e]) : silu_f(g[e]);
-          }
+        for (int e = 0; e < 8; ++e) { bv[ps][e] = 0.f; if (GLU) bg[ps][e] = 0.f; }
+        if (cok[ps] && (epi & LDM_EPI_BIAS)) {
+          load8(p.bias + ncol[ps], bv[ps]);
+          if (GLU) load8(p.bias + ncol[ps] + 16, bg[ps]);
         }
-        if (m >= p.M || ncol >= p.N) continue;
-        if (!glu) {
-          float t[8];
-          if (epi & LDM_EPI_BIAS) {
-            load8(p.bias + ncol, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-          }
-          if (epi & LDM_EPI_ROWVEC) {
-            load8(rowv + (size_t)(m / hw_out) * p.rowvec_stride + ncol, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-          }
-          if (epi & LDM_EPI_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-          }
-          if (epi & LDM_EPI_RESIDUAL) {
-            load8(resid + (size_t)m * p.N + ncol, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e];
-          }
-        }
-        if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * nout + ocol, v);
-        else store8(static_cast<bf16_t*>(p.out) + (size_t)m * nout + ocol, v);
       }
+      const bool has_res = !GLU && (epi & LDM_EPI_RESIDUAL), has_row = !GLU && (epi & LDM_EPI_ROWVEC);
+      uint4 rres[NPASS], rrow[NPASS];
+      auto fetch = [&](int i, uint4 (&qres)[NPASS], uint4 (&qrow)[NPASS]) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int m = mrow0 + i * 16 + row[ps];
+          qres[ps] = make_uint4(0, 0, 0, 0);
+          qrow[ps] = make_uint4(0, 0, 0, 0);
+          if (cok[ps] && m < p.M) {
+            if (has_res) qres[ps] = *reinterpret_cast<const uint4*>(resid + (size_t)m * p.N + ncol[ps]);
+            if (has_row) qrow[ps] = *reinterpret_cast<const uint4*>(rowv + (size_t)(m / hw_out) * p.rowvec_stride + ncol[ps]);
+          }
+        }
+      };
+      auto add_bf16x8 = [](float (&v)[8], const uint4& q) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += __uint_as_float(w[e] << 16);
+          v[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+      };
+      if (has_res || has_row) fetch(0, rres, rrow);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cst[(fq * 4 + r) * LDC + j * 16 + fr] = acc[i][j][r];
+        uint4 nres[NPASS], nrow[NPASS];
+        if ((has_res || has_row) && i + 1 < MI) fetch(i + 1, nres, nrow);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int m = mrow0 + i * 16 + row[ps];
+          if (!cok[ps] || m >= p.M) continue;
+          float v[8];
+          const float* src = cst + row[ps] * LDC + scol[ps];
+          const float4 x0 = *reinterpret_cast<const float4*>(src);
+          const float4 x1 = *reinterpret_cast<const float4*>(src + 4);
+          v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bv[ps][e];
+          if constexpr (GLU) {
+            const float4 g0 = *reinterpret_cast<const float4*>(src + 16);
+            const float4 g1 = *reinterpret_cast<const float4*>(src + 20);
+            float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            if (epi & LDM_EPI_GEGLU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_fast(g[e] + bg[ps][e]);
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] *= silu_fast(g[e] + bg[ps][e]);
+            }
+          } else {
+            if (has_row) add_bf16x8(v, rrow[ps]);
+            if (epi & LDM_EPI_SILU) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+            }
+            if (has_res) add_bf16x8(v, rres[ps]);
+          }
+          if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * nout + ocol[ps], v);
+          else store8(static_cast<bf16_t*>(p.out) + (size_t)m * nout + ocol[ps], v);
+        }
+        if (i + 1 < MI) {
+#pragma unroll
+          for (int ps = 0; ps < NPASS; ++ps) { rres[ps] = nres[ps]; rrow[ps] = nrow[ps]; }
+        }
+      }
+    };
+    if (glu) {
+      if constexpr (NI % 2 == 0) run(std::true_type{});
+    } else {
+      run(std::false_type{});
     }
+    LDM_STAMP(4);
+    LDM_STAMP(6);
     return;
   }
 #pragma unroll
@@ -386,7 +449,8 @@ conv_gemm_f32_kernel(const ConvGemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tile = blockIdx.x;
-  const int tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+  int tm, tn;
+  tile_to_mn(tile, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const float* a0 = static_cast<const float*>(p.a0);
   const float* a1 = static_cast<const float*>(p.a1);
@@ -516,6 +580,10 @@ conv_gemm_f32_kernel(const ConvGemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------ launch
+#ifdef LDM_GEMM_STAMPS
+static unsigned long long* g_stamp_buf = nullptr;
+static long long g_stamp_blocks = 0;
+#endif
 template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2>
 static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -528,6 +596,9 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
     if (e != hipSuccess) { set_error("ldm_conv_gemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
     attr_done = true;
   }
+#ifdef LDM_GEMM_STAMPS
+  p.stamps = (long long)p.tiles_m * p.tiles_n <= g_stamp_blocks ? g_stamp_buf : nullptr;
+#endif
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(bf16)");
   return LDM_OK;
@@ -586,6 +657,14 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, int& bm, int& bn, 
 
 using namespace ldm;
 
+#ifdef LDM_GEMM_STAMPS
+extern "C" int ldm_debug_set_stamps(unsigned long long* buf, long long blocks) {
+  g_stamp_buf = buf;
+  g_stamp_blocks = blocks;
+  return LDM_OK;
+}
+#endif
+
 extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   LDM_REQUIRE(d != nullptr, "ldm_conv_gemm: null descriptor");
   LDM_REQUIRE(dtype_ok(d->dtype) && dtype_ok(d->out_dtype), "ldm_conv_gemm: bad dtype");
@@ -623,6 +702,9 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.residual = d->residual; p.out = d->out;
   p.out_f32 = d->out_dtype == LDM_F32;
   p.vec_epilogue = 0;
+#ifdef LDM_GEMM_STAMPS
+  p.stamps = nullptr;
+#endif
   hipStream_t st = (hipStream_t)stream;
 
   if (d->dtype == LDM_F32) {

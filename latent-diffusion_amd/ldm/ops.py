@@ -124,7 +124,8 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
             e1.record()
             m = batch * hout * wout
             _launch_log.append((f"conv_gemm_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel<{tile[0]},{tile[1]},{tile[2]}>",
-                                2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1))
+                                2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1,
+                                (m, n, ksize * ksize * (c0 + c1), ksize, stride, int(bool(upsample)), c1, epi)))
     return out
 
 
@@ -132,7 +133,8 @@ _launch_log = None
 
 
 def set_launch_log(log):
-    """bench.py hook: a list that receives (kernel name, algorithmic FLOPs, start event, end event) per GEMM launch."""
+    """bench.py hook: a list that receives (kernel name, algorithmic FLOPs, start event, end event,
+    (M, N, K, ksize, stride, upsample, c1, epilogue flags)) per GEMM launch."""
     global _launch_log
     _launch_log = log
 
