@@ -37,7 +37,7 @@ struct ConvGemmParams {
   int tiles_m, tiles_n;
   int vec_epilogue; // 16-byte epilogue accesses are legal (alignment and n % 8 checked on the host)
 #ifdef LDM_GEMM_STAMPS
-  unsigned long long* stamps;  // diagnostic build only (make stamps): 8 cycle stamps per workgroup
+  unsigned long long* stamps;  // diagnostic build only (make stamps): 16 cycle stamps per workgroup
 #endif
 };
 
@@ -47,7 +47,7 @@ struct ConvGemmParams {
 #define LDM_STAMP(i)                                                                                      \
   do {                                                                                                    \
     if (p.stamps != nullptr && threadIdx.x == 0)                                                          \
-      p.stamps[(size_t)blockIdx.x * 8 + (i)] = (i) >= 5 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
+      p.stamps[(size_t)blockIdx.x * 16 + (i)] = ((i) == 5 || (i) == 6) ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define LDM_STAMP(i) do {} while (0)
@@ -241,9 +241,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     LDM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
+      if (kt == 8) LDM_STAMP(8);
       if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      if (kt == 8) LDM_STAMP(9);
       compute(cur);
+      if (kt == 8) LDM_STAMP(10);
       __syncthreads();
+      if (kt == 8) LDM_STAMP(11);
     }
   } else {
     // 3-slot ring, ONE raw barrier per K-tile, the LDS-DMA of the tile after next stays in flight across it:
@@ -263,10 +267,14 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      if (kt == 8) LDM_STAMP(8);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (kt == 8) LDM_STAMP(9);
       if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+      if (kt == 8) LDM_STAMP(10);
       compute(slot);
+      if (kt == 8) LDM_STAMP(11);
       slot = slot == 2 ? 0 : slot + 1;
     }
     __syncthreads();  // tile buffers become the epilogue's staging area

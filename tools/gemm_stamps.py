@@ -27,10 +27,11 @@ def main():
     lib.ldm_debug_set_stamps.restype = C.c_int
     dev = torch.device("cuda")
     cap = 1 << 17
-    buf = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(cap * 16, dtype=torch.int64, device=dev)
     g = torch.Generator(device=dev).manual_seed(0)
     print(f"{'case':28s} {'tile':>10s} {'blocks':>6s} | {'setup':>6s} {'fill':>6s} {'loop':>7s} {'cyc/kt':>6s} {'epi':>6s} {'total':>7s} | "
           f"{'us':>7s} {'wg/CU':>5s} {'clkGHz':>6s}")
+    print("kt8 columns: 2-stage tiles = stage issue, math, barrier(+DMA wait); 3-slot ring = barrier, stage issue, math")
     for name, (H, W, c0, c1), N, ks, stride, up, glu in CASES:
         if sel and not any(s in name for s in sel):
             continue
@@ -51,7 +52,7 @@ def main():
         lib.ldm_debug_set_stamps(None, 0)
         ops.set_launch_log(None)
         tile = log[-1][0][log[-1][0].index("<"):]
-        st = buf.cpu().numpy().reshape(cap, 8)
+        st = buf.cpu().numpy().reshape(cap, 16)
         st = st[st[:, 0] != 0]
         if len(st) == 0:
             print(f"{name:28s} {tile:>10s}  (too many workgroups for the stamp buffer)")
@@ -63,8 +64,12 @@ def main():
         span = (st[:, 6].max() - st[:, 5].min()) * 10e-9            # seconds (100 MHz)
         busy = ((st[:, 6] - st[:, 5]) * 10e-9).sum()
         clk = np.median((st[:, 4] - st[:, 0]) / np.maximum((st[:, 6] - st[:, 5]) * 10e-9, 1e-9)) / 1e9
+        inner = ""
+        if (st[:, 8] != 0).all():   # K-tile 8 of the main loop: the four sub-phases between stamps 8..11
+            di = np.median(np.diff(st[:, 8:12], axis=1).astype(np.float64), axis=0)
+            inner = f" | kt8: {di[0]:5.0f} {di[1]:5.0f} {di[2]:5.0f}"
         print(f"{name:28s} {tile:>10s} {len(st):6d} | {med[0]:6.0f} {med[1]:6.0f} {med[2]:7.0f} {med[2] / (K // bk):6.0f} {med[3]:6.0f} "
-              f"{tot:7.0f} | {span * 1e6:7.1f} {busy / span / 256:5.2f} {clk:6.2f}", flush=True)
+              f"{tot:7.0f} | {span * 1e6:7.1f} {busy / span / 256:5.2f} {clk:6.2f}{inner}", flush=True)
 
 
 if __name__ == "__main__":
