@@ -6,9 +6,12 @@
 //   orientation, S^T = K Q^T and O^T = V^T P^T: a lane then owns one query column, so the softmax is in-lane
 //   except for one 4-way max, and the S^T accumulators are, after packing to bf16, directly the B operand of the
 //   PV product (no LDS round trip for P).  V^T fragments come from ds_read_b64_tr_b16 (hardware transpose).
-//   K/V tiles are register-staged: the global loads of tile t+1 are issued before the math of tile t.
+//   K/V tiles are register-staged into two LDS buffers: the loads of tile t+2 are issued, and tile t+1 is
+//   committed, before the math of tile t; one barrier per tile.
 // generic path (float32, or head dims the MFMA path does not take): one wave per query, fp32 math.
 #include "common.h"
+
+#include <type_traits>
 
 namespace ldm {
 
@@ -30,30 +33,63 @@ struct AttnParams {
   int batch, heads, lq, lk;
   float scale_log2e;  // (1/sqrt(d)) * log2(e)
   float scale;
+#ifdef LDM_GEMM_STAMPS
+  unsigned long long* stamps;  // diagnostic build only (make stamps): 16 cycle stamps per workgroup
+#endif
 };
+
+#ifdef LDM_GEMM_STAMPS
+#define ATT_STAMP(i)                                                                                          \
+  do {                                                                                                        \
+    if (p.stamps != nullptr && threadIdx.x == 0)                                                              \
+      p.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (i)] =         \
+          __builtin_amdgcn_s_memtime();                                                                       \
+  } while (0)
+#else
+#define ATT_STAMP(i) do {} while (0)
+#endif
 
 template <int D>
 struct AttnGeom {
   static constexpr int KS = (D + 31) / 32;             // 32-deep contraction steps of Q K^T
   static constexpr int DK = KS * 32;
-  static constexpr int DT = (D + 15) / 16;             // 16-row tiles of O^T
+  static constexpr int DT = D / 16 + 1 - (D % 16 == 0 ? 1 : 0);  // 16-row tiles of O^T
   static constexpr int KROW = DK * 2 + 16;             // bytes per key row of the K image (+16: bank spread)
   static constexpr int VROW = (DT % 2 == 1 ? DT : DT + 1) * 32;  // odd multiple of 32 B: tr reads conflict-free
   static constexpr int K_BYTES = 64 * KROW;
   static constexpr int V_BYTES = 64 * VROW;
+  static constexpr int BUF_BYTES = K_BYTES + V_BYTES;  // one key tile (K image then V image); two of them in LDS
   static constexpr int CPR = D / 8;                    // 16-byte chunks per row in global memory
   static constexpr int NCH = (64 * CPR + 255) / 256;   // chunks per thread per tile and operand
+  // D not a multiple of 16: the V image has pad columns.  Column D is set to 1.0 once, so row D of O^T accumulates
+  // sum_k P[k] on the matrix core and the softmax denominator costs no vector adds.
+  static constexpr bool ONES = (D % 16) != 0;
 };
+
+// 16 bytes per lane from a raw buffer (base, bytes): `buffer_load_dwordx4 v, v, s[rsrc], s offen`.  voff is the
+// per-lane byte offset, soff a wave-uniform one; an offset past `bytes` reads zeros (key rows past lk).
+__device__ __forceinline__ uint4 buffer_load16(const void* base, unsigned bytes, unsigned voff, unsigned soff) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
 
 // D <= 80: two waves per SIMD (<= 256 registers), which also makes hipcc keep the MFMA accumulators in VGPRs
 // (with 512 registers allowed it parks them in AGPRs and pays ~200 v_accvgpr moves per key tile for the rescale).
+//
+// The loop is vector-ALU bound at d = 40 (per 64-key tile a wave runs 28 MFMAs but 32 exponentials per lane), so
+// everything else is kept off the vector ALU: K/V staging addresses are loop-invariant per-lane offsets plus a scalar
+// tile offset (buffer loads; rows past lk read as zeros), the ragged-tile mask exists only in the last tile's code,
+// the running maximum is only raised (and O rescaled) when some query's maximum grew by more than 2^8, and for
+// d = 40 the denominator comes out of the PV product (AttnGeom::ONES).  One barrier per key tile: tile t+1 is
+// committed to the other LDS buffer while tile t is being consumed.
 template <int D>
 __global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
 attention_bf16_kernel(const AttnParams p) {
   using G = AttnGeom<D>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* klds = smem;
-  unsigned char* vlds = smem + G::K_BYTES;
+  ATT_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -64,10 +100,14 @@ attention_bf16_kernel(const AttnParams p) {
   const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
   const bf16_t* vp = static_cast<const bf16_t*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * D;
   bf16_t* op = static_cast<bf16_t*>(p.out) + (size_t)b * p.lq * p.out_stride + h * D;
+  const unsigned kv_bytes = ((unsigned)(p.lk - 1) * p.kv_stride + D) * 2u;   // this (sample, head)'s rows, < 2 GiB (host)
 
-  // zero the whole LDS image once: pad columns are never written again and must not hold NaN patterns
-  for (int i = tid * 16; i < G::K_BYTES + G::V_BYTES; i += 256 * 16)
+  // zero both LDS images once: pad columns are never written again and must not hold NaN patterns
+  for (int i = tid * 16; i < 2 * G::BUF_BYTES; i += 256 * 16)
     *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  if (G::ONES && tid < 128)
+    *reinterpret_cast<bf16_t*>(smem + (tid >> 6) * G::BUF_BYTES + G::K_BYTES + (tid & 63) * G::VROW + D * 2) = 0x3F80;  // 1.0
 
   // Q^T fragments (B operand): lane (query fr, k-group fq) holds Q[query][32*ks + 8*fq + 0..7]
   bf16x8_t qf[2][G::KS];
@@ -91,42 +131,42 @@ attention_bf16_kernel(const AttnParams p) {
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
 
+  // staging geometry of this thread: loop-invariant
+  unsigned g_off[G::NCH];       // byte offset of the chunk inside a key tile (global), or out of range
+  int k_lds[G::NCH], v_lds[G::NCH];
+#pragma unroll
+  for (int c = 0; c < G::NCH; ++c) {
+    const int idx = c * 256 + tid;
+    const int row = idx / G::CPR, ch = idx - row * G::CPR;
+    const bool ok = idx < 64 * G::CPR;
+    g_off[c] = ok ? ((unsigned)row * p.kv_stride + ch * 8) * 2u : 0x80000000u;
+    k_lds[c] = ok ? row * G::KROW + ch * 16 : -1;
+    v_lds[c] = G::K_BYTES + row * G::VROW + ch * 16;
+  }
   uint4 kreg[G::NCH], vreg[G::NCH];
-  auto fetch = [&](int t0) {
+  auto fetch = [&](int t) {
+    const unsigned soff = (unsigned)t * 64u * p.kv_stride * 2u;
 #pragma unroll
     for (int c = 0; c < G::NCH; ++c) {
-      const int idx = c * 256 + tid;
-      const int row = idx / G::CPR, ch = idx - row * G::CPR;
-      uint4 kz = make_uint4(0, 0, 0, 0), vz = kz;
-      if (idx < 64 * G::CPR && t0 + row < p.lk) {
-        kz = *reinterpret_cast<const uint4*>(kp + (size_t)(t0 + row) * p.kv_stride + ch * 8);
-        vz = *reinterpret_cast<const uint4*>(vp + (size_t)(t0 + row) * p.kv_stride + ch * 8);
-      }
-      kreg[c] = kz;
-      vreg[c] = vz;
+      kreg[c] = buffer_load16(kp, kv_bytes, g_off[c], soff);
+      vreg[c] = buffer_load16(vp, kv_bytes, g_off[c], soff);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](unsigned char* buf) {
 #pragma unroll
     for (int c = 0; c < G::NCH; ++c) {
-      const int idx = c * 256 + tid;
-      const int row = idx / G::CPR, ch = idx - row * G::CPR;
-      if (idx < 64 * G::CPR) {
-        *reinterpret_cast<uint4*>(klds + row * G::KROW + ch * 16) = kreg[c];
-        *reinterpret_cast<uint4*>(vlds + row * G::VROW + ch * 16) = vreg[c];
+      if (k_lds[c] >= 0) {
+        *reinterpret_cast<uint4*>(buf + k_lds[c]) = kreg[c];
+        *reinterpret_cast<uint4*>(buf + v_lds[c]) = vreg[c];
       }
     }
   };
 
-  const int ntiles = (p.lk + 63) / 64;
-  fetch(0);
-  for (int t = 0; t < ntiles; ++t) {
-    const int t0 = t * 64;
-    __syncthreads();           // everyone is done reading the previous tile (and the zero fill)
-    commit();
-    __syncthreads();
-    if (t + 1 < ntiles) fetch(t0 + 64);   // in flight under the math below
-
+  const int tq = fr >> 2, tp = fr & 3;
+  auto tile = [&](auto ragged_tag, const unsigned char* buf, int t0) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const unsigned char* klds = buf;
+    const unsigned char* vlds = buf + G::K_BYTES;
     // ---- S^T = K Q^T : s[g][kb] holds keys kb*16 + 4*fq + r of query fr
     f32x4_t s[2][4];
 #pragma unroll
@@ -142,7 +182,7 @@ attention_bf16_kernel(const AttnParams p) {
         s[1][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[1][ks], s[1][kb], 0, 0, 0);
       }
     }
-    if (t0 + 64 > p.lk) {  // ragged last tile: keys past lk get -inf
+    if constexpr (RAGGED) {  // keys past lk get -inf
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -161,23 +201,33 @@ attention_bf16_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[g][kb][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[g], mx * p.scale_log2e);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-      m_run[g] = m_new;
-      float psum = 0.f;
+      const float ms = mx * p.scale_log2e;
+      // Lazy maximum: probabilities are taken relative to m_run, which is only raised when some query of this group
+      // saw its maximum grow by more than 8 (p <= 2^8: harmless in fp32 and in bf16).  Wave-uniform branch.
+      if (__builtin_amdgcn_ballot_w64(ms > m_run[g] + 8.0f) != 0) {
+        const float m_new = fmaxf(m_run[g], ms);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+        m_run[g] = m_new;
+        if (!G::ONES) l_run[g] *= alpha;
+#pragma unroll
+        for (int t2 = 0; t2 < G::DT; ++t2) {
+          o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
+        }
+      }
+      const float mr = m_run[g];
       float pv[4][4];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(s[g][kb][r] * p.scale_log2e - m_new);  // raw v_exp_f32: arguments <= 0
-          pv[kb][r] = e;
-          psum += e;
-        }
-      l_run[g] = l_run[g] * alpha + psum;
+        for (int r = 0; r < 4; ++r)
+          pv[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[g][kb][r], p.scale_log2e, -mr));  // raw v_exp_f32: arguments <= 8
+      if (!G::ONES) {
+        float psum = 0.f;
 #pragma unroll
-      for (int t2 = 0; t2 < G::DT; ++t2) {
-        o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) psum += pv[kb][r];
+        l_run[g] += psum;
       }
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
@@ -193,7 +243,6 @@ attention_bf16_kernel(const AttnParams p) {
     }
 
     // ---- O^T += V^T P^T : V^T fragments by transposed LDS reads (4 keys x 16 dims per 16-lane group)
-    const int tq = fr >> 2, tp = fr & 3;
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
 #pragma unroll
@@ -207,14 +256,41 @@ attention_bf16_kernel(const AttnParams p) {
         o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pb[1][st], o[1][dt], 0, 0, 0);
       }
     }
+  };
+
+  const int ntiles = (p.lk + 63) / 64;
+  fetch(0);
+  commit(smem);
+  if (ntiles > 1) fetch(1);
+  ATT_STAMP(1);
+  for (int t = 0; t < ntiles; ++t) {
+    unsigned char* cur = smem + (t & 1) * G::BUF_BYTES;
+    unsigned char* nxt = smem + ((t + 1) & 1) * G::BUF_BYTES;
+    if (t == 8) ATT_STAMP(2);
+    __syncthreads();   // tile t is in `cur` for every wave, and every wave is done reading `nxt` (tile t-1)
+    if (t == 8) ATT_STAMP(3);
+    if (t + 1 < ntiles) {
+      commit(nxt);                        // tile t+1: its loads were issued a whole tile ago
+      if (t + 2 < ntiles) fetch(t + 2);   // in flight under the math below
+    }
+    if (t == 8) ATT_STAMP(4);
+    if (t + 1 == ntiles && (p.lk & 63) != 0) tile(std::true_type{}, cur, t * 64);
+    else tile(std::false_type{}, cur, t * 64);
+    if (t == 8) ATT_STAMP(7);
   }
+  ATT_STAMP(8);
 
   // ---- normalise and store: lane holds dims dt*16 + 4*fq + 0..3 of query fr
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    float l = l_run[g];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l;
+    if (G::ONES) {   // row D of O^T: tile D/16, lanes fq == (D%16)/4, register (D%16)%4
+      l = __shfl(o[g][D / 16][(D % 16) % 4], ((D % 16) / 4) * 16 + fr, 64);
+    } else {
+      l = l_run[g];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+    }
     const float inv = 1.0f / l;
     const int qi = q0 + g * 16 + fr;
     if (qi >= p.lq) continue;
@@ -314,7 +390,14 @@ attention_generic_kernel(const AttnParams p, int d) {
 template <int D>
 static int launch_mfma(const AttnParams& p, hipStream_t st) {
   using G = AttnGeom<D>;
-  const int smem = G::K_BYTES + G::V_BYTES;
+  const int smem = 2 * G::BUF_BYTES;
+  static bool attr_done = false;   // > 64 KiB of dynamic LDS needs the opt-in once per process
+  if (smem > 64 * 1024 && !attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bf16_kernel<D>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("ldm_attention: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+    attr_done = true;
+  }
   dim3 grid((p.lq + 127) / 128, p.heads, p.batch);
   hipLaunchKernelGGL((attention_bf16_kernel<D>), grid, dim3(256), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_attention(bf16 mfma)");
@@ -324,6 +407,16 @@ static int launch_mfma(const AttnParams& p, hipStream_t st) {
 }  // namespace ldm
 
 using namespace ldm;
+
+#ifdef LDM_GEMM_STAMPS
+static unsigned long long* g_att_stamp_buf = nullptr;
+static long long g_att_stamp_blocks = 0;
+extern "C" int ldm_debug_set_attention_stamps(unsigned long long* buf, long long blocks) {
+  g_att_stamp_buf = buf;
+  g_att_stamp_blocks = blocks;
+  return LDM_OK;
+}
+#endif
 
 extern "C" int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
                              int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, void* stream) {
@@ -339,10 +432,13 @@ extern "C" int ldm_attention(const void* q, int q_stride, const void* k, const v
   p.batch = batch; p.heads = heads; p.lq = lq; p.lk = lk;
   p.scale = 1.0f / sqrtf((float)d);
   p.scale_log2e = p.scale * 1.4426950408889634f;
+#ifdef LDM_GEMM_STAMPS
+  p.stamps = (long long)((lq + 127) / 128) * heads * batch <= g_att_stamp_blocks ? g_att_stamp_buf : nullptr;
+#endif
   hipStream_t st = (hipStream_t)stream;
   const bool vec_ok = aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                       q_stride % 8 == 0 && kv_stride % 8 == 0 && out_stride % 4 == 0;
-  if (dtype == LDM_BF16 && vec_ok) {
+  if (dtype == LDM_BF16 && vec_ok && (long long)lk * kv_stride * 2 < (1LL << 31)) {
     switch (d) {
       case 40: return launch_mfma<40>(p, st);
       case 64: return launch_mfma<64>(p, st);
