@@ -128,6 +128,11 @@ typedef struct LdmConvGemm {
   void* out;                   /* [m][n] (or [m][n/2] with GEGLU/SWIGLU) */
   int32_t dtype;               /* LDM_BF16 (MFMA bf16, fp32 accumulate) or LDM_F32 (exact fp32 MFMA) */
   int32_t out_dtype;           /* dtype of out; normally == dtype */
+  /* Optional DEVICE scratch the call may use for split-K partial sums (small-M layers that cannot fill the chip
+   * otherwise: the 8x8 level of the UNet).  NULL / 0: never split.  Contents are undefined afterwards; calls
+   * sharing one workspace must be ordered on one stream.  The result is deterministic either way. */
+  void* workspace;
+  int64_t workspace_bytes;
 } LdmConvGemm;
 
 /* out = epilogue(im2col(A) @ W^T).  M = batch*hout*wout rows.  Replaces nn.Conv2d 3x3/1x1 and nn.Linear

@@ -64,7 +64,14 @@ struct AttnGeom {
   // D not a multiple of 16: the V image has pad columns.  Column D is set to 1.0 once, so row D of O^T accumulates
   // sum_k P[k] on the matrix core and the softmax denominator costs no vector adds.
   static constexpr bool ONES = (D % 16) != 0;
+  // D not a multiple of 32: the contraction of Q K^T has pad columns.  Column D of the K image is set to 1.0 once and
+  // column D of the Q fragment holds -m (the running maximum), Q itself is pre-multiplied by log2(e)/sqrt(d): the
+  // matrix core then delivers s*scale - m directly and the softmax needs no multiply-add per score.
+  static constexpr bool AUG = (D % 32) != 0;
+  static constexpr int AUG_KS = D / 32, AUG_FQ = (D % 32) / 8, AUG_E = D % 8;
 };
+
+__device__ __forceinline__ float round_to_bf16(float x) { return __uint_as_float(cvt_pk_bf16(x, 0.0f) << 16); }
 
 // 16 bytes per lane from a raw buffer (base, bytes): `buffer_load_dwordx4 v, v, s[rsrc], s offen`.  voff is the
 // per-lane byte offset, soff a wave-uniform one; an offset past `bytes` reads zeros (key rows past lk).
@@ -108,6 +115,8 @@ attention_bf16_kernel(const AttnParams p) {
   __syncthreads();
   if (G::ONES && tid < 128)
     *reinterpret_cast<bf16_t*>(smem + (tid >> 6) * G::BUF_BYTES + G::K_BYTES + (tid & 63) * G::VROW + D * 2) = 0x3F80;  // 1.0
+  if (G::AUG && tid >= 128)
+    *reinterpret_cast<bf16_t*>(smem + ((tid - 128) >> 6) * G::BUF_BYTES + (tid & 63) * G::KROW + D * 2) = 0x3F80;
 
   // Q^T fragments (B operand): lane (query fr, k-group fq) holds Q[query][32*ks + 8*fq + 0..7]
   bf16x8_t qf[2][G::KS];
@@ -119,6 +128,14 @@ attention_bf16_kernel(const AttnParams p) {
       const int col = ks * 32 + fq * 8;
       bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
       if (qi < p.lq && col < D) z = *reinterpret_cast<const bf16x8_t*>(qp + (size_t)qi * p.q_stride + col);
+      if (G::AUG) {  // Q * log2(e)/sqrt(d), rounded to bf16 again
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const uint32_t w = cvt_pk_bf16(bf16_to_f32((bf16_t)z[e]) * p.scale_log2e, bf16_to_f32((bf16_t)z[e + 1]) * p.scale_log2e);
+          z[e] = (short)(w & 0xffffu);
+          z[e + 1] = (short)(w >> 16);
+        }
+      }
       qf[g][ks] = z;
     }
   }
@@ -128,7 +145,7 @@ attention_bf16_kernel(const AttnParams p) {
   for (int g = 0; g < 2; ++g)
 #pragma unroll
     for (int t = 0; t < G::DT; ++t) o[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-INFINITY, -INFINITY};
+  float m_run[2] = {G::AUG ? 0.f : -INFINITY, G::AUG ? 0.f : -INFINITY};   // AUG: column D of Q holds -m_run = 0
   float l_run[2] = {0.f, 0.f};
 
   // staging geometry of this thread: loop-invariant
@@ -163,7 +180,7 @@ attention_bf16_kernel(const AttnParams p) {
   };
 
   const int tq = fr >> 2, tp = fr & 3;
-  auto tile = [&](auto ragged_tag, const unsigned char* buf, int t0) {
+  auto tile = [&](auto ragged_tag, const unsigned char* buf, int t0, bool first) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     const unsigned char* klds = buf;
     const unsigned char* vlds = buf + G::K_BYTES;
@@ -201,26 +218,54 @@ attention_bf16_kernel(const AttnParams p) {
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[g][kb][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float ms = mx * p.scale_log2e;
-      // Lazy maximum: probabilities are taken relative to m_run, which is only raised when some query of this group
-      // saw its maximum grow by more than 8 (p <= 2^8: harmless in fp32 and in bf16).  Wave-uniform branch.
-      if (__builtin_amdgcn_ballot_w64(ms > m_run[g] + 8.0f) != 0) {
-        const float m_new = fmaxf(m_run[g], ms);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
-        m_run[g] = m_new;
-        if (!G::ONES) l_run[g] *= alpha;
-#pragma unroll
-        for (int t2 = 0; t2 < G::DT; ++t2) {
-          o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
-        }
-      }
-      const float mr = m_run[g];
       float pv[4][4];
+      if constexpr (G::AUG) {
+        // s already is score*scale - m_run.  Lazy maximum: m_run is raised (and O rescaled) only when some query of
+        // this group sees a value above 8 (p <= 2^8: harmless in fp32 and in bf16), or in the first tile, where it is
+        // set to the tile maximum whatever its sign.  m_run stays bf16-representable so that the copy inside the Q
+        // fragment is exact.  Wave-uniform branch.
+        const bool raise = first || mx > 8.0f;
+        if (__builtin_amdgcn_ballot_w64(raise) != 0) {
+          const float m_new = round_to_bf16(m_run[g] + (raise ? mx : 0.f));
+          const float d2 = m_new - m_run[g];
+          const float alpha = __builtin_amdgcn_exp2f(-d2);
+          m_run[g] = m_new;
+          if (!G::ONES) l_run[g] *= alpha;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+          for (int t2 = 0; t2 < G::DT; ++t2) {
+            o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
+          }
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          pv[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[g][kb][r], p.scale_log2e, -mr));  // raw v_exp_f32: arguments <= 8
+          for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[g][kb][r] -= d2;
+          if (fq == G::AUG_FQ) qf[g][G::AUG_KS][G::AUG_E] = (short)(__float_as_uint(-m_new) >> 16);
+        }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[kb][r] = __builtin_amdgcn_exp2f(s[g][kb][r]);   // raw v_exp_f32: arguments <= 8
+      } else {
+        const float ms = mx * p.scale_log2e;
+        // Lazy maximum: probabilities are taken relative to m_run, which is only raised when some query of this
+        // group saw its maximum grow by more than 8 (p <= 2^8: harmless in fp32 and in bf16).  Wave-uniform branch.
+        if (__builtin_amdgcn_ballot_w64(ms > m_run[g] + 8.0f) != 0) {
+          const float m_new = fmaxf(m_run[g], ms);
+          const float alpha = __builtin_amdgcn_exp2f(m_run[g] - m_new);
+          m_run[g] = m_new;
+          if (!G::ONES) l_run[g] *= alpha;
+#pragma unroll
+          for (int t2 = 0; t2 < G::DT; ++t2) {
+            o[g][t2][0] *= alpha; o[g][t2][1] *= alpha; o[g][t2][2] *= alpha; o[g][t2][3] *= alpha;
+          }
+        }
+        const float mr = m_run[g];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            pv[kb][r] = __builtin_amdgcn_exp2f(fmaf(s[g][kb][r], p.scale_log2e, -mr));  // raw v_exp_f32: arguments <= 8
+      }
       if (!G::ONES) {
         float psum = 0.f;
 #pragma unroll
@@ -274,8 +319,8 @@ attention_bf16_kernel(const AttnParams p) {
       if (t + 2 < ntiles) fetch(t + 2);   // in flight under the math below
     }
     if (t == 8) ATT_STAMP(4);
-    if (t + 1 == ntiles && (p.lk & 63) != 0) tile(std::true_type{}, cur, t * 64);
-    else tile(std::false_type{}, cur, t * 64);
+    if (t + 1 == ntiles && (p.lk & 63) != 0) tile(std::true_type{}, cur, t * 64, t == 0);
+    else tile(std::false_type{}, cur, t * 64, t == 0);
     if (t == 8) ATT_STAMP(7);
   }
   ATT_STAMP(8);

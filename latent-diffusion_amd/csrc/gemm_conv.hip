@@ -36,6 +36,8 @@ struct ConvGemmParams {
   int out_f32;      // out dtype is float32 (else same as compute dtype)
   int tiles_m, tiles_n;
   int vec_epilogue; // 16-byte epilogue accesses are legal (alignment and n % 8 checked on the host)
+  int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
+  float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
   unsigned long long* stamps;  // diagnostic build only (make stamps): 16 cycle stamps per workgroup
 #endif
@@ -155,8 +157,17 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     b_voff[it] = n < p.N ? ((unsigned)n * p.K + (cpos ^ swz<CH>(r)) * 8) * 2u : OOB;
   }
 
+  // this workgroup's K-tiles (all of them unless split-K)
+  const int nk_all = p.K / BK;
+  const int kt_begin = p.splits > 1 ? (int)((long long)blockIdx.y * nk_all / p.splits) : 0;
+  const int kt_end = p.splits > 1 ? (int)((long long)(blockIdx.y + 1) * nk_all / p.splits) : nk_all;
+  const int nk = kt_end - kt_begin;
+
   // K-loop iterator (block-uniform): tap -> source -> channel offset inside the source
-  int it_tap = 0, it_second = 0, it_cc = 0;
+  int it_tap = (kt_begin * BK) / p.ctot;
+  int it_cc = kt_begin * BK - it_tap * p.ctot;
+  int it_second = it_cc >= p.c0 ? 1 : 0;
+  if (it_second) it_cc -= p.c0;
   bool it_fresh = true;
   unsigned a_voff[A_IT];
   auto stage = [&](int buf, int kt) {
@@ -208,7 +219,6 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
-  const int nk = p.K / BK;
 
   auto compute = [&](int buf) {
     const unsigned char* sa = smem + buf * STAGE;
@@ -236,13 +246,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
 
   LDM_STAMP(1);
   if constexpr (STAGES == 2) {
-    stage(0, 0);
+    stage(0, kt_begin);
     __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
     LDM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       if (kt == 8) LDM_STAMP(8);
-      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+      if (kt + 1 < nk) stage(cur ^ 1, kt_begin + kt + 1);
       if (kt == 8) LDM_STAMP(9);
       compute(cur);
       if (kt == 8) LDM_STAMP(10);
@@ -257,8 +267,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // part in the partial last B pass) per tile.
     static_assert(STAGES == 3, "ring depth");
     const bool extra = B_IT > B_FULL && (B_FULL * NT + wave * 64) < BN * CH;
-    stage(0, 0);
-    if (nk > 1) stage(1, 1);
+    stage(0, kt_begin);
+    if (nk > 1) stage(1, kt_begin + 1);
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) {
@@ -271,7 +281,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt == 8) LDM_STAMP(9);
-      if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt + 2);
+      if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
       if (kt == 8) LDM_STAMP(10);
       compute(slot);
       if (kt == 8) LDM_STAMP(11);
@@ -282,11 +292,14 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
 
   LDM_STAMP(3);
   // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
-  const int epi = p.epilogue;
+  const bool split = p.splits > 1;           // raw fp32 partial sums, epilogue applied by splitk_reduce_kernel
+  const int epi = split ? 0 : p.epilogue;
   const bool glu = (epi & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
   const int nout = glu ? p.N >> 1 : p.N;
   const bf16_t* resid = static_cast<const bf16_t*>(p.residual);
   const bf16_t* rowv = static_cast<const bf16_t*>(p.rowvec);
+  void* const outp = split ? static_cast<void*>(p.partial + (size_t)blockIdx.y * p.M * p.N) : p.out;
+  const bool out_f32 = split || p.out_f32;
   if (p.vec_epilogue) {
     // Vector epilogue: each wave transposes its accumulators through LDS, 16 rows at a time, so that a lane owns 8
     // consecutive output columns: bias / time-embedding / residual operands and the result move as 16-byte accesses
@@ -386,8 +399,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             }
             if (has_res) add_bf16x8(v, rres[ps]);
           }
-          if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * nout + ocol[ps], v);
-          else store8(static_cast<bf16_t*>(p.out) + (size_t)m * nout + ocol[ps], v);
+          if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
+          else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
         }
         if (i + 1 < MI) {
 #pragma unroll
@@ -421,8 +434,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           if (epi & LDM_EPI_ROWVEC) v += bf16_to_f32(rowv[(size_t)sample * p.rowvec_stride + n]);
           if (epi & LDM_EPI_SILU) v = silu_f(v);
           if (epi & LDM_EPI_RESIDUAL) v += bf16_to_f32(resid[(size_t)m * p.N + n]);
-          if (p.out_f32) static_cast<float*>(p.out)[(size_t)m * p.N + n] = v;
-          else static_cast<bf16_t*>(p.out)[(size_t)m * p.N + n] = f32_to_bf16(v);
+          if (out_f32) static_cast<float*>(outp)[(size_t)m * p.N + n] = v;
+          else static_cast<bf16_t*>(outp)[(size_t)m * p.N + n] = f32_to_bf16(v);
         }
       } else {
         if constexpr (NI % 2 == 0) {
@@ -436,13 +449,53 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             const float g = (epi & LDM_EPI_GEGLU) ? gelu_erf_f(gate) : silu_f(gate);
             const int jo = ((n0 + wn * WTN + j * 16) >> 1) + fr;  // column in the [M][N/2] output
             const float v = val * g;
-            if (p.out_f32) static_cast<float*>(p.out)[(size_t)m * nout + jo] = v;
-            else static_cast<bf16_t*>(p.out)[(size_t)m * nout + jo] = f32_to_bf16(v);
+            if (out_f32) static_cast<float*>(outp)[(size_t)m * nout + jo] = v;
+            else static_cast<bf16_t*>(outp)[(size_t)m * nout + jo] = f32_to_bf16(v);
           }
         }
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------- split-K fold
+// out[m][n..n+8) = epilogue( sum_z partial[z][m][n..n+8) ), fixed z order (deterministic).  One lane per 8 columns.
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const ConvGemmParams p) {
+  const int cpr = p.N >> 3;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * cpr) return;
+  const int m = (int)(idx / cpr), n = (int)(idx - (long long)m * cpr) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.splits; ++z) {
+    float t[8];
+    load8(p.partial + ((size_t)z * p.M + m) * p.N + n, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  const int epi = p.epilogue;
+  float t[8];
+  if (epi & LDM_EPI_BIAS) {
+    load8(p.bias + n, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (epi & LDM_EPI_ROWVEC) {
+    load8(static_cast<const bf16_t*>(p.rowvec) + (size_t)(m / (p.hout * p.wout)) * p.rowvec_stride + n, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (epi & LDM_EPI_SILU) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = silu_fast(v[e]);
+  }
+  if (epi & LDM_EPI_RESIDUAL) {
+    load8(static_cast<const bf16_t*>(p.residual) + (size_t)m * p.N + n, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += t[e];
+  }
+  if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * p.N + n, v);
+  else store8(static_cast<bf16_t*>(p.out) + (size_t)m * p.N + n, v);
 }
 
 // ------------------------------------------------------------------------------------------- fp32
@@ -605,30 +658,40 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
     attr_done = true;
   }
 #ifdef LDM_GEMM_STAMPS
-  p.stamps = (long long)p.tiles_m * p.tiles_n <= g_stamp_blocks ? g_stamp_buf : nullptr;
+  p.stamps = (long long)p.tiles_m * p.tiles_n <= g_stamp_blocks && p.splits == 1 ? g_stamp_buf : nullptr;
 #endif
-  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n), dim3(64 * WM * WN), smem, st, p);
+  hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(64 * WM * WN), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(bf16)");
+  if (p.splits > 1) {
+    const long long chunks = (long long)p.M * (p.N / 8);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, p);
+    LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(split-K fold)");
+  }
   return LDM_OK;
 }
 
-static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per_cu) {
+// Expected efficiency of a (tile, split-K) choice: padding waste x chip fill x operand reuse x split-K overhead.
+static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per_cu, int splits) {
   const double tm = (p.M + BM - 1) / BM, tn = (p.N + BN - 1) / BN;
   const double tiles = tm * tn;
   const double useful = ((double)p.M * p.N) / (tiles * BM * BN);          // padding waste
   const double slots = 256.0 * blocks_per_cu;
-  const double rounds = ceil(tiles / slots);
-  const double fill = tiles / (rounds * slots);                            // tail / under-fill
+  const double blocks = tiles * splits;
+  const double rounds = ceil(blocks / slots);
+  const double fill = blocks / (rounds * slots);                           // tail / under-fill
   // operand reuse: 128-row tiles > 64-row tiles.  The 256-row, 8-wave, 3-slot-ring tiles measured equal to the
   // 128-row ones at best (profiles/r1_gemm_tile_sweep.txt), so they only win a tie-break on fill.
   const double size_bonus = BM >= 256 ? 0.97 : ((BM * BN >= 128 * 128) ? 1.0 : 0.85);
-  return useful * fill * size_bonus;
+  // split-K: every split adds an fp32 round trip of the output through the fold kernel
+  const double split_cost = 1.0 - 0.04 * (splits - 1);
+  return useful * fill * size_bonus * split_cost;
 }
 
 // Tile choice of the bf16 path: BK = 64 when no K-tile straddles a tap or a concat boundary, else 32;
-// among the BK = 64 tiles the one with the best (padding waste x chip fill) score; GLU epilogues need an even
-// number of 16-column tiles per wave, i.e. BN = 128.
-static void pick_tile_bf16(const ConvGemmParams& p, bool glu, int& bm, int& bn, int& bk) {
+// among the BK = 64 tiles (and, when the caller lent a workspace, split-K factors) the best score; GLU epilogues
+// need an even number of 16-column tiles per wave, i.e. BN = 128, and are never split.
+static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspace_bytes, int& bm, int& bn, int& bk, int& splits) {
+  splits = 1;
   const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
   if (!bk64) {
     bk = 32;
@@ -636,29 +699,27 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, int& bm, int& bn, 
     return;
   }
   bk = 64;
-  if (const char* force = getenv("LDM_GEMM_TILE")) {   // tuning knob (tools/gemm_bench.py): "BM,BN" of a BK=64 tile
-    int fm = 0, fn = 0;
-    if (sscanf(force, "%d,%d", &fm, &fn) == 2 && (fm == 64 || fm == 128 || fm == 256) && (fn == 128 || (fn == 160 && !glu))) {
+  if (const char* force = getenv("LDM_GEMM_TILE")) {   // tuning knob (tools/gemm_bench.py): "BM,BN[,splits]" of a BK=64 tile
+    int fm = 0, fn = 0, fs = 1;
+    const int got = sscanf(force, "%d,%d,%d", &fm, &fn, &fs);
+    if (got >= 2 && (fm == 64 || fm == 128 || fm == 256) && (fn == 128 || (fn == 160 && !glu))) {
       bm = fm; bn = fn;
+      if (got == 3 && fs >= 1 && fs <= 16 && !glu && (long long)fs * p.M * p.N * 4 <= workspace_bytes && p.K / 64 >= fs) splits = fs;
       return;
     }
   }
-  const double s_128_128 = tile_score(p, 128, 128, 2), s_64_128 = tile_score(p, 64, 128, 3);
-  const double s_256_128 = tile_score(p, 256, 128, 1);
-  if (glu) {
-    bn = 128;
-    bm = s_128_128 >= s_64_128 ? 128 : 64;
-    if (s_256_128 > (bm == 128 ? s_128_128 : s_64_128)) bm = 256;
-    return;
+  static const int cand[][3] = {{128, 128, 2}, {128, 160, 2}, {64, 128, 3}, {64, 160, 3}, {256, 128, 1}, {256, 160, 1}};
+  static const int split_cand[] = {1, 2, 3, 4, 6, 8};
+  const int nk = p.K / 64;
+  double best = -1.0;
+  for (const auto& c : cand) {
+    if (glu && c[1] != 128) continue;
+    for (int sp : split_cand) {
+      if (sp > 1 && (glu || nk / sp < 16 || (long long)sp * p.M * p.N * 4 > workspace_bytes)) continue;
+      const double sc = tile_score(p, c[0], c[1], c[2], sp);
+      if (sc > best) { best = sc; bm = c[0]; bn = c[1]; splits = sp; }
+    }
   }
-  const double s_128_160 = tile_score(p, 128, 160, 2), s_64_160 = tile_score(p, 64, 160, 3);
-  double best = s_128_128; bm = 128; bn = 128;
-  if (s_128_160 > best) { best = s_128_160; bm = 128; bn = 160; }
-  if (s_64_128 > best) { best = s_64_128; bm = 64; bn = 128; }
-  if (s_64_160 > best) { best = s_64_160; bm = 64; bn = 160; }
-  const double s_256_160 = tile_score(p, 256, 160, 1);
-  if (s_256_128 > best) { best = s_256_128; bm = 256; bn = 128; }
-  if (s_256_160 > best) { best = s_256_160; bm = 256; bn = 160; }
 }
 
 }  // namespace ldm
@@ -710,6 +771,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.residual = d->residual; p.out = d->out;
   p.out_f32 = d->out_dtype == LDM_F32;
   p.vec_epilogue = 0;
+  p.splits = 1;
+  p.partial = nullptr;
 #ifdef LDM_GEMM_STAMPS
   p.stamps = nullptr;
 #endif
@@ -744,7 +807,9 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     p.vec_epilogue = ok ? 1 : 0;
   }
   int bm, bn, bk;
-  pick_tile_bf16(p, glu, bm, bn, bk);
+  const bool ws_ok = d->workspace != nullptr && aligned16(d->workspace) && p.vec_epilogue;
+  pick_tile_bf16(p, glu, ws_ok ? d->workspace_bytes : 0, bm, bn, bk, p.splits);
+  p.partial = static_cast<float*>(d->workspace);
   const int key = bm * 1000000 + bn * 1000 + bk;
   switch (key) {
     case 64064032: return launch_bf16<64, 64, 32, 2, 2>(p, st);
@@ -767,7 +832,9 @@ extern "C" int ldm_conv_gemm_tile(const LdmConvGemm* d, int tile[3]) {
   ConvGemmParams p;
   p.c0 = d->c0; p.c1 = d->c1; p.ctot = d->c0 + d->c1;
   p.M = d->batch * d->hout * d->wout; p.N = d->n;
+  p.K = d->ksize * d->ksize * p.ctot;
   const bool glu = (d->epilogue & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
-  pick_tile_bf16(p, glu, tile[0], tile[1], tile[2]);
+  int splits;
+  pick_tile_bf16(p, glu, d->workspace ? d->workspace_bytes : 0, tile[0], tile[1], tile[2], splits);
   return LDM_OK;
 }

@@ -80,23 +80,33 @@ gn_partial_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, 
   }
 }
 
-// stage 2: fold the slabs in double, emit mean / rstd
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nslabs, int groups, int total, double count,
-                                   float eps, float* __restrict__ stats) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over batch*groups
+// stage 2: fold the slabs in double, emit mean / rstd.  One wave per (sample, group): a lane takes one slab, the fold
+// is a fixed butterfly (deterministic); a single thread walking 64 dependent loads took 15 us per launch.
+__global__ void __launch_bounds__(256)
+gn_finalize_kernel(const float* __restrict__ partial, int nslabs, int groups, int total, double count,
+                   float eps, float* __restrict__ stats) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);  // over batch*groups
+  const int lane = threadIdx.x & 63;
   if (i >= total) return;
   const int b = i / groups, grp = i - b * groups;
   double a = 0.0, q = 0.0;
-  for (int s = 0; s < nslabs; ++s) {
+  for (int s = lane; s < nslabs; s += 64) {
     const float* o = partial + (((size_t)b * nslabs + s) * groups + grp) * 2;
     a += (double)o[0];
     q += (double)o[1];
   }
-  const double mean = a / count;
-  double var = q / count - mean * mean;
-  var = var < 0.0 ? 0.0 : var;
-  stats[2 * i] = (float)mean;
-  stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    q += __shfl_xor(q, o, 64);
+  }
+  if (lane == 0) {
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    stats[2 * i] = (float)mean;
+    stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <typename T>
@@ -249,7 +259,7 @@ extern "C" int ldm_groupnorm_stats(const void* a0, const void* a1, int c0, int c
     hipLaunchKernelGGL((gn_partial_kernel<float>), grid, dim3(GN_THREADS), smem, st, (const float*)a0, (const float*)a1, g, workspace);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_stats(partial)");
   const int total = batch * groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, st, workspace, nslabs, groups, total,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 3) / 4), dim3(256), 0, st, workspace, nslabs, groups, total,
                      (double)hw * g.cpg, eps, stats);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_stats(finalize)");
   return LDM_OK;

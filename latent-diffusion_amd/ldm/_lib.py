@@ -19,7 +19,9 @@ F32, BF16 = 0, 1
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU, EPI_GEGLU, EPI_SWIGLU = 1, 2, 4, 8, 16, 32
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libldm_amd.so")
+# LDM_AMD_LIB overrides the path (A/B runs of two builds of the library; there is still no fallback).
+_LIB_PATH = os.environ.get("LDM_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                          "lib", "libldm_amd.so")
 
 c_void_p, c_int, c_i64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PF = C.POINTER(C.c_float)
@@ -43,6 +45,7 @@ class ConvGemmDesc(C.Structure):
         ("bias", c_void_p), ("rowvec", c_void_p), ("rowvec_stride", C.c_int32),
         ("residual", c_void_p), ("out", c_void_p),
         ("dtype", C.c_int32), ("out_dtype", C.c_int32),
+        ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

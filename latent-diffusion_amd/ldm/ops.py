@@ -112,6 +112,9 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
                      ksize=ksize, stride=stride, upsample=1 if upsample else 0, w=w.data_ptr(), n=n, epilogue=epi,
                      bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
                      residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
+    if a0.dtype == torch.bfloat16 and batch * hout * wout <= _SPLITK_MAX_ROWS:
+        ws = _splitk_workspace(a0.device)   # small-M layers may split K; ordered by the current stream like `out`
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     with torch.cuda.device(a0.device):
         if _launch_log is None:
             _lib.check(_lib.load().ldm_conv_gemm(C.byref(d), _stream(a0)), "ldm_conv_gemm")
@@ -130,6 +133,19 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
 
 
 _launch_log = None
+
+_SPLITK_MAX_ROWS = 4096                 # only layers this small are ever offered the workspace
+_SPLITK_WORKSPACE_FLOATS = 16 << 20     # 64 MiB per device: 8 splits of a 2048 x 1280 output
+_splitk_ws = {}
+
+
+def _splitk_workspace(device) -> torch.Tensor:
+    """Per-(device, stream) scratch lent to ldm_conv_gemm for split-K partial sums (struct LdmConvGemm.workspace)."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _splitk_ws.get(key)
+    if ws is None:
+        ws = _splitk_ws[key] = torch.empty(_SPLITK_WORKSPACE_FLOATS, dtype=torch.float32, device=device)
+    return ws
 
 
 def set_launch_log(log):

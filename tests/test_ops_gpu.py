@@ -201,6 +201,37 @@ def test_every_bf16_tile(tile, monkeypatch):
     assert list(t) == [bm, bn, 64], list(t)
 
 
+@pytest.mark.parametrize("tile", [None, "64,128,2", "128,128,3", "128,160,4", "256,128,2", "64,160,8"])
+def test_split_k(tile, monkeypatch):
+    """Small-M layers (the 8x8 level) split K over blockIdx.y into a lent workspace and fold deterministically:
+    3x3 conv with two sources + time embedding + bias, and linear + bias + SiLU + residual into float32."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    if tile:
+        monkeypatch.setenv("LDM_GEMM_TILE", tile)
+    B, c0, c1, H, W, Cout = 5, 128, 64, 8, 8, 320
+    a, ar = _q(nhwc(seeded((B, c0, H, W), 1)), dtype)
+    s_, sr = _q(nhwc(seeded((B, c1, H, W), 2)), dtype)
+    w = seeded((Cout, c0 + c1, 3, 3), 3) / math.sqrt(9 * (c0 + c1))
+    b = seeded((Cout,), 4)
+    rv, rvr = _q(seeded((B, Cout), 5), dtype)
+    wp = ops.pack_weight(w.cuda(), dtype)
+    y = ops.conv_gemm(a, wp, a1=s_, ksize=3, bias=b.cuda(), rowvec=rv)
+    y2 = ops.conv_gemm(a, wp, a1=s_, ksize=3, bias=b.cuda(), rowvec=rv)
+    assert torch.equal(y, y2)   # deterministic fold
+    cat = torch.cat([ar, sr], dim=-1).permute(0, 3, 1, 2)
+    ref = nhwc(F.conv2d(cat, w.to(dtype).float(), b, padding=1) + rvr[:, :, None, None])
+    assert rel_l2(y, ref) < TOL[dtype]
+    x, xr = _q(seeded((300, 2048), 6), dtype)
+    wl = seeded((328, 2048), 7) / math.sqrt(2048)
+    res, resr = _q(seeded((300, 328), 8), dtype)
+    bl = seeded((328,), 9)
+    wlp = ops.pack_weight(wl.cuda(), dtype)
+    y = ops.conv_gemm(x, wlp, bias=bl.cuda(), silu=True, residual=res, out_dtype=torch.float32)
+    ref = F.silu(F.linear(xr, wlp.float().cpu(), bl)) + resr
+    assert y.dtype == torch.float32 and rel_l2(y, ref) < 2e-5 + 1e-3  # SiLU by v_exp/v_rcp: ~1e-6 relative
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32

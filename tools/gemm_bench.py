@@ -40,6 +40,9 @@ def main():
     tiles = [None]
     if "--sweep" in sys.argv:   # every BK=64 tile the library instantiates, forced through LDM_GEMM_TILE
         tiles = [None, "64,128", "64,160", "128,128", "128,160", "256,128", "256,160"]
+    if "--splits" in sys.argv:  # split-K variants (only honoured for small-M cases, where ops lends the workspace)
+        tiles = [None, "64,128", "64,128,2", "64,128,3", "128,128,2", "128,128,3", "128,128,4", "128,160,2", "128,160,4",
+                 "128,160,6", "256,160,4", "256,160,8"]
     for name, (H, W, c0, c1), N, ks, stride, up, glu in CASES:
         if sel and not any(s in name for s in sel):
             continue
@@ -52,7 +55,7 @@ def main():
         for tile in tiles:
             if tile is None:
                 os.environ.pop("LDM_GEMM_TILE", None)
-            elif glu and tile.endswith("160"):
+            elif glu and tile.split(",")[1] == "160":
                 continue
             else:
                 os.environ["LDM_GEMM_TILE"] = tile
