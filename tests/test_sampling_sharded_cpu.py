@@ -1,0 +1,108 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run the sharded sampling loop (ldm/sampling.py) with a stand-in
+denoiser and the oracle scheduler (the HIP kernels need a GPU; the sharding, the shard-independent noise, the final
+all-gather and the max-over-ranks timing are host logic).  The gathered result must equal the single-process result
+bit for bit."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "latent-diffusion_amd"))
+sys.path.insert(0, ROOT)
+
+
+class OracleScheduler:
+    """CPU stand-in with the product scheduler's interface, backed by oracle/scheduler_ref.py."""
+
+    def __init__(self):
+        from oracle import scheduler_ref as sref
+        self.sref = sref
+        self.tabs = sref.build_tables()
+        self.init_noise_sigma = 1.0
+        self.timesteps = None
+
+    def set_timesteps(self, n, **kwargs):
+        self.timesteps = self.sref.inference_timesteps(n, 1000, "leading", 0)
+        self.n = n
+
+    def scale_model_input(self, x, t=None):
+        return x
+
+    def step(self, eps, t, x, noise=None, guidance=None):
+        if guidance is not None:
+            eps_c, g = guidance
+            eps = eps + g * (eps_c - eps)
+        t = int(t)
+        s = int(self.sref.previous_timestep(self.timesteps, t, True))
+        prev, x0 = self.sref.step(self.tabs, eps, t, s, x, noise)
+        return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
+
+
+def toy_denoiser(x, t, ctx):
+    # per-sample arithmetic only, like the UNet (no batch-coupled op)
+    return 0.1 * torch.tanh(x) + ctx.mean(dim=(1, 2)).reshape(-1, 1, 1, 1) * 0.01 + float(t) * 1e-4
+
+
+def run_sampler(rank, world, n, steps, guidance):
+    from ldm import sampling
+    g = torch.Generator().manual_seed(7)
+    ctx = torch.randn(n, 5, 8, generator=g)
+    unc = torch.randn(1, 5, 8, generator=g)
+    return sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, latent_shape=(4, 6, 6), num_inference_steps=steps,
+                                   guidance_scale=guidance, uncond_ctx=unc if guidance else None, seed=3, rank=rank,
+                                   world=world, device=torch.device("cpu"))
+
+
+def _worker(rank, world, port, n, steps, guidance, out_dir):
+    from ldm import sampling
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        local = run_sampler(rank, world, n, steps, guidance)
+        lo, hi = sampling.shard_range(n, rank, world)
+        assert local.shape[0] == hi - lo
+        full = sampling.gather_latents(local, n, rank, world)
+        slow = sampling.max_over_ranks(1.0 + rank, torch.device("cpu"), world)
+        assert slow == float(world)
+        if rank == 0:
+            torch.save(full, os.path.join(out_dir, "full.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_range_partitions():
+    from ldm import sampling
+    for n in (0, 1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [sampling.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        sampling.shard_range(8, 2, 2)
+
+
+def test_noise_is_independent_of_the_sharding():
+    from ldm import sampling
+    full = sampling.global_noise(11, 4, (9, 4, 3, 3), 0, 9, torch.device("cpu"))
+    parts = [sampling.global_noise(11, 4, (9, 4, 3, 3), *sampling.shard_range(9, r, 4), torch.device("cpu")) for r in range(4)]
+    assert torch.equal(torch.cat(parts), full)
+    assert not torch.equal(full, sampling.global_noise(11, 5, (9, 4, 3, 3), 0, 9, torch.device("cpu")))
+
+
+@pytest.mark.parametrize("guidance", [None, 7.5])
+def test_two_gloo_ranks_match_one_process(tmp_path, guidance):
+    n, steps, world = 7, 6, 2     # 7 rows: ragged shards (4 + 3)
+    ref = run_sampler(0, 1, n, steps, guidance)
+    port = 29500 + (os.getpid() % 2000) + (1 if guidance else 0)
+    mp.spawn(_worker, args=(world, port, n, steps, guidance, str(tmp_path)), nprocs=world, join=True)
+    full = torch.load(os.path.join(str(tmp_path), "full.pt"), weights_only=True)
+    assert full.shape == ref.shape
+    assert torch.equal(full, ref)

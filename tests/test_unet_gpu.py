@@ -205,3 +205,43 @@ def test_trajectory_config1(golden):
     psnr = 10 * math.log10(float(ref.max() - ref.min()) ** 2 / mse)
     print(f"50-step sample PSNR vs reference: {psnr:.1f} dB")
     assert psnr > 40.0  # stated floor: torch fp32 vs fp64 on this chain is 47.4 dB
+
+
+# ------------------------------------------------------------------------------- sharded sampling loop
+def test_sampling_shards_match_whole_batch():
+    """ldm/sampling.py on the GPU (SURVEY 8e, config 3 in miniature): 6 latents, 8 steps, small UNet, float32.
+    Two emulated ranks (3 + 3 latents) must reproduce the single-rank batch: the noise is a function of the global
+    sample index and the UNet has no batch-coupled op.  Not bit-exact: split-K / tile choice depend on the batch."""
+    from ldm import sampling
+    from ldm.scheduling_ddpm import DDPMScheduler
+    net, _, _ = _small_unet()
+    ctx = seeded((6, 77, 768), 21).cuda()
+    kw = dict(latent_shape=(4, 16, 16), num_inference_steps=8, seed=5)
+    whole = sampling.sample_latents(net, DDPMScheduler(device=torch.device("cuda")), ctx, **kw)
+    parts = [sampling.sample_latents(net, DDPMScheduler(device=torch.device("cuda")), ctx, rank=r, world=2, **kw)
+             for r in range(2)]
+    assert whole.shape == (6, 4, 16, 16) and parts[0].shape[0] == 3
+    assert rel_l2(torch.cat(parts), whole) < 1e-4
+
+
+def test_sampling_with_guidance_matches_manual_loop():
+    """Classifier-free guidance (train_latent_diffusion.py:581-593): the fused CFG step against the reference's
+    own order of operations (cat -> forward -> chunk -> combine -> step) written with the product modules."""
+    from ldm import sampling
+    from ldm.scheduling_ddpm import DDPMScheduler
+    net, _, _ = _small_unet()
+    ctx = seeded((2, 77, 768), 22).cuda()
+    unc = seeded((1, 77, 768), 23).cuda()
+    kw = dict(latent_shape=(4, 16, 16), num_inference_steps=5, seed=9)
+    got = sampling.sample_latents(net, DDPMScheduler(device=torch.device("cuda")), ctx, guidance_scale=7.5,
+                                  uncond_ctx=unc, **kw)
+    sch = DDPMScheduler(device=torch.device("cuda"))
+    sch.set_timesteps(5, device="cuda")
+    lat = sampling.global_noise(9, -1, (2, 4, 16, 16), 0, 2, torch.device("cuda"))
+    emb = torch.cat([unc.expand(2, -1, -1), ctx])
+    with torch.no_grad():
+        for i, t in enumerate(sch.timesteps):
+            eps_u, eps_c = net(torch.cat([lat, lat]), t, emb).chunk(2)
+            eps = eps_u + 7.5 * (eps_c - eps_u)
+            lat = sch.step(eps, t, lat, noise=sampling.global_noise(9, i, (2, 4, 16, 16), 0, 2, torch.device("cuda"))).prev_sample
+    assert rel_l2(got, lat) < 1e-4
