@@ -100,8 +100,17 @@ attention_bf16_kernel(const AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // Workgroup -> (sample, head, query block): consecutive workgroup ids alternate over the 8 XCDs, so give every XCD a
+  // contiguous run of the (sample, head, query block) order: the query blocks of one (sample, head) then share its
+  // K/V through ONE L2 instead of fetching them into all eight (FETCH_SIZE was 4.5x the K/V bytes).
+  const int nqb = gridDim.x;
+  const int nblk = nqb * gridDim.y * gridDim.z;
+  const int lin = (blockIdx.z * gridDim.y + blockIdx.y) * nqb + blockIdx.x;
+  const int xq = nblk >> 3, xr = nblk & 7, xcd = lin & 7;
+  const int work = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+  const int bh = work / nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = (work - bh * nqb) * 128 + wave * 32;
 
   const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
   const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;

@@ -7,6 +7,16 @@ namespace ldm {
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAX_SLABS = 64;   // partial-sum slabs per sample (see ldm_groupnorm_stats)
 constexpr int GN_MAX_CHUNKS = 4;   // 8-channel chunks per thread -> C <= 8 * 256 * 4
+constexpr int GN_UNROLL = 4;       // pixels in flight per thread in the streaming loops
+
+__device__ __forceinline__ void unpack8(const uint4& r, float (&v)[8]) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
 
 // Thread layout shared by the two GroupNorm kernels: CT threads across the 8-channel chunks of a pixel,
 // PIX = 256 / CT pixels per pass; a thread keeps its channel chunk(s) for the whole kernel.
@@ -39,6 +49,39 @@ gn_partial_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[k][j] = ss[k][j] = 0.f;
   if (active) {
+    if (g.nchunks <= g.ct) {
+      // one chunk per thread (C <= 2048): GN_UNROLL pixels in flight per thread -- a single 16-byte load per
+      // loop trip left the kernel latency-bound at 45 % of the HBM rate
+      const int cc = tc;
+      int p = p_begin + tp;
+      for (; p + (GN_UNROLL - 1) * g.pix < p_end; p += GN_UNROLL * g.pix) {
+        uint4 raw[GN_UNROLL];
+        float4 rawf[GN_UNROLL][2];
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+          int cs;
+          const T* src = gn_src(a0, a1, g, (int64_t)b * g.hw + p + u * g.pix, cc * 8, cs);
+          if constexpr (sizeof(T) == 2) raw[u] = *reinterpret_cast<const uint4*>(src);
+          else { rawf[u][0] = *reinterpret_cast<const float4*>(src); rawf[u][1] = *reinterpret_cast<const float4*>(src + 4); }
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UNROLL; ++u) {
+          float v[8];
+          if constexpr (sizeof(T) == 2) unpack8(raw[u], v);
+          else { v[0] = rawf[u][0].x; v[1] = rawf[u][0].y; v[2] = rawf[u][0].z; v[3] = rawf[u][0].w;
+                 v[4] = rawf[u][1].x; v[5] = rawf[u][1].y; v[6] = rawf[u][1].z; v[7] = rawf[u][1].w; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[0][j] += v[j]; ss[0][j] += v[j] * v[j]; }
+        }
+      }
+      for (; p < p_end; p += g.pix) {
+        int cs;
+        float v[8];
+        load8(gn_src(a0, a1, g, (int64_t)b * g.hw + p, cc * 8, cs), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[0][j] += v[j]; ss[0][j] += v[j] * v[j]; }
+      }
+    } else {
     for (int p = p_begin + tp; p < p_end; p += g.pix) {
       const int64_t pixel = (int64_t)b * g.hw + p;
 #pragma unroll
@@ -52,6 +95,7 @@ gn_partial_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, 
           for (int j = 0; j < 8; ++j) { s[k][j] += v[j]; ss[k][j] += v[j] * v[j]; }
         }
       }
+    }
     }
 #pragma unroll
     for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
@@ -135,7 +179,29 @@ gn_apply_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, co
       }
     }
   }
-  for (int p = p_begin + tp; p < p_end; p += g.pix) {
+  int p = p_begin + tp;
+  if (g.nchunks <= g.ct) {   // one chunk per thread: GN_UNROLL pixels in flight (see gn_partial_kernel)
+    const int cc = tc;
+    for (; p + (GN_UNROLL - 1) * g.pix < p_end; p += GN_UNROLL * g.pix) {
+      float v[GN_UNROLL][8];
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+        int cs;
+        load8(gn_src(a0, a1, g, (int64_t)b * g.hw + p + u * g.pix, cc * 8, cs), v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < GN_UNROLL; ++u) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = v[u][j] * sc[0][j] + sh[0][j];
+          if (silu) y = sizeof(T) == 2 ? silu_fast(y) : silu_f(y);   // bf16 output: raw v_exp/v_rcp form
+          v[u][j] = y;
+        }
+        store8(out + ((int64_t)b * g.hw + p + u * g.pix) * g.ctot + cc * 8, v[u]);
+      }
+    }
+  }
+  for (; p < p_end; p += g.pix) {
     const int64_t pixel = (int64_t)b * g.hw + p;
 #pragma unroll
     for (int k = 0; k < GN_MAX_CHUNKS; ++k) {
@@ -147,7 +213,7 @@ gn_apply_kernel(const T* __restrict__ a0, const T* __restrict__ a1, GnGeom g, co
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float y = v[j] * sc[k][j] + sh[k][j];
-          if (silu) y = silu_f(y);
+          if (silu) y = sizeof(T) == 2 ? silu_fast(y) : silu_f(y);   // bf16 output: raw v_exp/v_rcp form
           v[j] = y;
         }
         store8(out + pixel * g.ctot + cc * 8, v);
@@ -181,51 +247,83 @@ static int gn_geom(int c0, int c1, int hw, int groups, int batch, GnGeom& g, int
 
 // ------------------------------------------------------------------------------------- LayerNorm
 constexpr int LN_MAX_CHUNKS = 8;  // per lane -> cols <= 4096
-
-template <typename T>
+// One wave normalises ROWS rows at a time, a lane holding CPL 8-element chunks of each: all ROWS*CPL loads are in
+// flight before the first reduction (one row per wave with one or two loads in flight ran at 45 % of the HBM rate).
+// (ROWS, CPL) by width: C <= 512 -> (4, 1); C <= 1024 -> (2, 2); C <= 2048 -> (1, 4); C <= 4096 -> (1, 8).
+template <typename T, int ROWS, int CPL>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const T* __restrict__ x, int64_t rows, int cols, float eps, const float* __restrict__ gamma,
                  const float* __restrict__ beta, T* __restrict__ out) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
   const int nchunks = cols >> 3;
-  const T* xr = x + row * cols;
-  float v[LN_MAX_CHUNKS][8];
-  float s = 0.f;
+  float v[ROWS][CPL][8];
 #pragma unroll
-  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int cc = lane + k * 64;
+      if (cc < nchunks && row0 + r < rows) load8(x + (row0 + r) * cols + cc * 8, v[r][k]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[r][k][j] = 0.f;
+      }
+    }
+  float g[CPL][8], b[CPL][8];
+#pragma unroll
+  for (int k = 0; k < CPL; ++k) {
     const int cc = lane + k * 64;
-    if (cc < nchunks) {
-      load8(xr + cc * 8, v[k]);
+    if (cc < nchunks) { load8(gamma + cc * 8, g[k]); load8(beta + cc * 8, b[k]); }
+  }
+  const float inv_n = 1.0f / (float)cols;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[k][j];
+  for (int r = 0; r < ROWS; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[r][k][j];
+    const float mean = wave_sum(s) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      if (lane + k * 64 < nchunks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[r][k][j] - mean; q += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_n + eps);
+    if (row0 + r >= rows) continue;
+    T* orow = out + (row0 + r) * cols;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+      const int cc = lane + k * 64;
+      if (cc < nchunks) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (v[r][k][j] - mean) * rstd * g[k][j] + b[k][j];
+        store8(orow + cc * 8, y);
+      }
     }
   }
-  const float mean = wave_sum(s) / (float)cols;
-  float q = 0.f;
-#pragma unroll
-  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
-    const int cc = lane + k * 64;
-    if (cc < nchunks) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; q += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)cols + eps);
-  T* orow = out + row * cols;
-#pragma unroll
-  for (int k = 0; k < LN_MAX_CHUNKS; ++k) {
-    const int cc = lane + k * 64;
-    if (cc < nchunks) {
-      float g[8], b[8], y[8];
-      load8(gamma + cc * 8, g);
-      load8(beta + cc * 8, b);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = (v[k][j] - mean) * rstd * g[j] + b[j];
-      store8(orow + cc * 8, y);
-    }
-  }
+}
+
+template <typename T, int ROWS, int CPL>
+static void launch_layernorm(const void* x, int64_t rows, int cols, float eps, const float* gamma, const float* beta, void* out,
+                             hipStream_t st) {
+  const int64_t waves = (rows + ROWS - 1) / ROWS;
+  hipLaunchKernelGGL((layernorm_kernel<T, ROWS, CPL>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, (const T*)x, rows, cols,
+                     eps, gamma, beta, (T*)out);
+}
+
+template <typename T>
+static void dispatch_layernorm(const void* x, int64_t rows, int cols, float eps, const float* gamma, const float* beta, void* out,
+                               hipStream_t st) {
+  if (cols <= 512) launch_layernorm<T, 4, 1>(x, rows, cols, eps, gamma, beta, out, st);
+  else if (cols <= 1024) launch_layernorm<T, 2, 2>(x, rows, cols, eps, gamma, beta, out, st);
+  else if (cols <= 2048) launch_layernorm<T, 1, 4>(x, rows, cols, eps, gamma, beta, out, st);
+  else launch_layernorm<T, 1, 8>(x, rows, cols, eps, gamma, beta, out, st);
 }
 
 }  // namespace ldm
@@ -300,11 +398,8 @@ extern "C" int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, f
   LDM_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), "ldm_layernorm: buffers must be 16-byte aligned");
   LDM_REQUIRE((rows + 3) / 4 < (1LL << 31), "ldm_layernorm: too many rows");
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)((rows + 3) / 4));
-  if (dtype == LDM_BF16)
-    hipLaunchKernelGGL((layernorm_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows, cols, eps, gamma, beta, (bf16_t*)out);
-  else
-    hipLaunchKernelGGL((layernorm_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows, cols, eps, gamma, beta, (float*)out);
+  if (dtype == LDM_BF16) dispatch_layernorm<bf16_t>(x, rows, cols, eps, gamma, beta, out, st);
+  else dispatch_layernorm<float>(x, rows, cols, eps, gamma, beta, out, st);
   LDM_HIP_CHECK_LAUNCH("ldm_layernorm");
   return LDM_OK;
 }
