@@ -170,9 +170,16 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   if (it_second) it_cc -= p.c0;
   bool it_fresh = true;
   unsigned a_voff[A_IT];
-  auto stage = [&](int buf, int kt) {
-    unsigned char* sa = smem + buf * STAGE;
-    unsigned char* sb = sa + A_BYTES;
+  // A K-tile is staged as NPIECE wave-instructions of 1 KiB (A_IT of A, then B_IT of the filter).  stage_begin fixes
+  // the tile's addressing state and advances the iterator; stage_piece(i) issues one of them, so the ring loop can
+  // spread them between its MFMAs.
+  constexpr int NPIECE = A_IT + B_IT;
+  const void* st_abase = p.a0;
+  unsigned st_abytes = bytes_a0;
+  int st_soff_a = 0, st_soff_b = 0;
+  unsigned char* st_sa = smem;
+  auto stage_begin = [&](int buf, int kt) {
+    st_sa = smem + buf * STAGE;
     const int cs = it_second ? p.c1 : p.c0;
     if (it_fresh) {                          // new (tap, source): per-lane offsets change
       const int kh = it_tap / p.ksize, kw = it_tap - kh * p.ksize;
@@ -185,23 +192,10 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       }
       it_fresh = false;
     }
-    const int soff_a = it_cc * 2;
-    if (it_second) {
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it)
-        dma16_to_lds(p.a1, bytes_a1, sa + (it * NT + wave * 64) * 16, a_voff[it], soff_a);
-    } else {
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it)
-        dma16_to_lds(p.a0, bytes_a0, sa + (it * NT + wave * 64) * 16, a_voff[it], soff_a);
-    }
-    const int soff_b = kt * (BK * 2);
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      if (it < B_FULL || (it * NT + wave * 64) < BN * CH) {   // wave-uniform
-        dma16_to_lds(p.w, bytes_w, sb + (it * NT + wave * 64) * 16, b_voff[it], soff_b);
-      }
-    }
+    st_abase = it_second ? p.a1 : p.a0;
+    st_abytes = it_second ? bytes_a1 : bytes_a0;
+    st_soff_a = it_cc * 2;
+    st_soff_b = kt * (BK * 2);
     // advance the iterator
     it_cc += BK;
     if (it_cc >= cs) {
@@ -211,6 +205,22 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       else { it_second = 0; ++it_tap; }
     }
   };
+  auto stage_piece = [&](auto piece_tag) {
+    constexpr int PI = decltype(piece_tag)::value;
+    if constexpr (PI < A_IT) {
+      dma16_to_lds(st_abase, st_abytes, st_sa + (PI * NT + wave * 64) * 16, a_voff[PI], st_soff_a);
+    } else if constexpr (PI < NPIECE) {
+      constexpr int it = PI - A_IT;
+      if (it < B_FULL || (it * NT + wave * 64) < BN * CH)   // wave-uniform
+        dma16_to_lds(p.w, bytes_w, st_sa + A_BYTES + (it * NT + wave * 64) * 16, b_voff[it], st_soff_b);
+    }
+  };
+  auto stage_all = [&](auto... tags) { (stage_piece(tags), ...); };
+  auto stage = [&](int buf, int kt) {
+    stage_begin(buf, kt);
+    [&]<int... I>(std::integer_sequence<int, I...>) { stage_all(std::integral_constant<int, I>{}...); }
+    (std::make_integer_sequence<int, NPIECE>{});
+  };
 
   f32x4_t acc[MI][NI];
 #pragma unroll
@@ -219,6 +229,47 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     for (int j = 0; j < NI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
+
+  // Ring loop body: the math of one K-tile with the LDS-DMA pieces of the tile two ahead issued between the MFMAs
+  // (one piece every GAP MFMAs).  Issued in one burst after the barrier, the pieces of all 8 waves queue behind the
+  // CU's ~38 B/clk L2->LDS path for ~1,200 cycles during which no wave can issue an MFMA; spread out, the matrix
+  // cores run while the path drains.
+  auto compute_and_stage = [&](int buf, bool do_stage) {
+    const unsigned char* sa = smem + buf * STAGE;
+    const unsigned char* sb = sa + A_BYTES;
+    constexpr int NMFMA = KS * MI * NI;
+    constexpr int GAP = NMFMA / (NPIECE + 1) > 0 ? NMFMA / (NPIECE + 1) : 1;
+    [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+      ([&] {
+        constexpr int ks = KSI;
+        bf16x8_t af[MI], bfr[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int row = wm * WTM + i * 16 + fr;
+          af[i] = *reinterpret_cast<const bf16x8_t*>(sa + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int row = wn * WTN + j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+        }
+        [&]<int... IJ>(std::integer_sequence<int, IJ...>) {
+          ([&] {
+            constexpr int i = IJ / NI, j = IJ % NI;
+            constexpr int seq = ks * MI * NI + IJ;           // MFMA number inside the K-tile
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if constexpr ((seq + 1) % GAP == 0 && (seq + 1) / GAP - 1 < NPIECE) {
+              if (do_stage) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_piece(std::integral_constant<int, (seq + 1) / GAP - 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          }(), ...);
+        }(std::make_integer_sequence<int, MI * NI>{});
+      }(), ...);
+    }(std::make_integer_sequence<int, KS>{});
+  };
 
   auto compute = [&](int buf) {
     const unsigned char* sa = smem + buf * STAGE;
@@ -281,9 +332,10 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (kt == 8) LDM_STAMP(9);
-      if (kt + 2 < nk) stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+      const bool more = kt + 2 < nk;
+      if (more) stage_begin(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
       if (kt == 8) LDM_STAMP(10);
-      compute(slot);
+      compute_and_stage(slot, more);
       if (kt == 8) LDM_STAMP(11);
       slot = slot == 2 ? 0 : slot + 1;
     }
@@ -679,9 +731,10 @@ static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per
   const double blocks = tiles * splits;
   const double rounds = ceil(blocks / slots);
   const double fill = blocks / (rounds * slots);                           // tail / under-fill
-  // operand reuse: 128-row tiles > 64-row tiles.  The 256-row, 8-wave, 3-slot-ring tiles measured equal to the
-  // 128-row ones at best (profiles/r1_gemm_tile_sweep.txt), so they only win a tie-break on fill.
-  const double size_bonus = BM >= 256 ? 0.97 : ((BM * BN >= 128 * 128) ? 1.0 : 0.85);
+  // operand reuse: 256x160 (8 waves, 3-slot ring, DMA issue spread between the MFMAs) measured 2-9 % ahead of 128x160
+  // on the large layers and 256x128 behind 128x128 (profiles/r1_gemm_tile_sweep.txt); 64-row tiles stage 40 % more
+  // bytes per FLOP.
+  const double size_bonus = BM >= 256 ? (BN == 160 ? 1.04 : 0.97) : ((BM * BN >= 128 * 128) ? 1.0 : 0.85);
   // split-K: every split adds an fp32 round trip of the output through the fold kernel
   const double split_cost = 1.0 - 0.04 * (splits - 1);
   return useful * fill * size_bonus * split_cost;
