@@ -144,6 +144,16 @@ int ldm_conv_gemm(const LdmConvGemm* desc, void* stream);
  * attribute measured launch times to kernel instantiations).  No counterpart in the reference. */
 int ldm_conv_gemm_tile(const LdmConvGemm* desc, int tile[3]);
 
+/* Weight gradient of the same layer: dw[n][ci][kh][kw] (+)= sum_m dy[m][n] * im2col(A)[m][(kh,kw,ci)], float32 in the
+ * checkpoint layout (OIHW / [out,in]) -- what loss.backward() (train_latent_diffusion.py:1117) leaves in the .grad of
+ * every nn.Conv2d / nn.Linear weight of ldm/unet.py.  `desc` describes the forward call (A operand, geometry, n, dtype;
+ * w / epilogue / out are ignored); dy is [m][n] in desc->dtype.  accumulate != 0 adds to dw (gradient accumulation,
+ * :1032).  `workspace`: DEVICE scratch of at least ldm_conv_wgrad_workspace_bytes(desc) bytes (fp32 partial tiles of
+ * the pixel splits, folded in a fixed order: deterministic).  bf16 only this round. */
+long long ldm_conv_wgrad_workspace_bytes(const LdmConvGemm* desc);
+int ldm_conv_wgrad(const LdmConvGemm* desc, const void* dy, float* dw, int accumulate, void* workspace,
+                   long long workspace_bytes, void* stream);
+
 /* --------------------------------------------------------------------------- UNet: normalisation */
 
 /* Per-(sample, group) mean and rstd over an NHWC tensor (two-source virtual concat allowed).

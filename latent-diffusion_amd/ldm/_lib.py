@@ -62,6 +62,7 @@ _SIGNATURES = {
     "ldm_pack_weight": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "ldm_conv_gemm": [C.POINTER(ConvGemmDesc), c_void_p],
     "ldm_conv_gemm_tile": [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int)],
+    "ldm_conv_wgrad": [C.POINTER(ConvGemmDesc), c_void_p, c_void_p, c_int, c_void_p, C.c_longlong, c_void_p],
     "ldm_groupnorm_workspace_floats": [c_int, c_int],
     "ldm_groupnorm_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                             c_void_p, c_void_p],
@@ -78,7 +79,7 @@ _SIGNATURES = {
                      c_void_p],
 }
 
-EXPORTED_SYMBOLS = ["ldm_abi_version", "ldm_last_error"] + list(_SIGNATURES)
+EXPORTED_SYMBOLS = ["ldm_abi_version", "ldm_last_error", "ldm_conv_wgrad_workspace_bytes"] + list(_SIGNATURES)
 
 _lib = None
 
@@ -104,6 +105,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = c_int
         fn.argtypes = argtypes
+    lib.ldm_conv_wgrad_workspace_bytes.restype = C.c_longlong
+    lib.ldm_conv_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvGemmDesc)]
     if lib.ldm_abi_version() != 1:
         raise LdmError(f"ABI version mismatch: library reports {lib.ldm_abi_version()}, binding expects 1")
     _lib = lib

@@ -132,6 +132,62 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
     return out
 
 
+def conv_wgrad(a0: torch.Tensor, dy: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
+               upsample: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight gradient of conv_gemm(a0, w, a1=..., ksize=..., stride=..., upsample=...): float32, checkpoint layout
+    ([N, C0+C1, k, k], or [N, C] for ksize == 1 matrices).  ``out``: an existing gradient to accumulate into."""
+    _gpu(a0, a1, dy, out)
+    if a0.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
+        raise TypeError("conv_wgrad: bf16 activations and output gradients (the float32 path is not built yet)")
+    if not a0.is_contiguous() or not dy.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
+        raise ValueError("conv_wgrad: activations and dy must be contiguous")
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    n = dy.shape[-1]
+    if ksize == 1 and not upsample and stride == 1:
+        rows = a0.numel() // c0
+        batch, hin, win, hout, wout = rows, 1, 1, 1, 1
+        shape = (n, c0 + c1)
+    else:
+        if a0.dim() != 4:
+            raise ValueError("conv_wgrad: 3x3 / strided / upsampled convs take (B, H, W, C) inputs")
+        batch, hin, win = a0.shape[0], a0.shape[1], a0.shape[2]
+        hs, ws = (2 * hin, 2 * win) if upsample else (hin, win)
+        pad = ksize // 2
+        hout = (hs + 2 * pad - ksize) // stride + 1
+        wout = (ws + 2 * pad - ksize) // stride + 1
+        shape = (n, c0 + c1, ksize, ksize)
+    if dy.numel() != batch * hout * wout * n:
+        raise ValueError(f"conv_wgrad: dy has {dy.numel()} elements, expected {batch * hout * wout}x{n}")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=a0.device)
+    elif out.dtype != torch.float32 or tuple(out.shape) != shape or not out.is_contiguous():
+        raise ValueError(f"conv_wgrad: out must be a contiguous float32 tensor of shape {shape}")
+    d = ConvGemmDesc(a0=a0.data_ptr(), a1=_ptr(a1), c0=c0, c1=c1, batch=batch, hin=hin, win=win, hout=hout, wout=wout,
+                     ksize=ksize, stride=stride, upsample=1 if upsample else 0, n=n, dtype=dt_code(a0.dtype),
+                     out_dtype=dt_code(a0.dtype))
+    lib = _lib.load()
+    need = lib.ldm_conv_wgrad_workspace_bytes(C.byref(d))
+    ws = _wgrad_workspace(a0.device, need)
+    with torch.cuda.device(a0.device):
+        _lib.check(lib.ldm_conv_wgrad(C.byref(d), dy.data_ptr(), out.data_ptr(), 1 if accumulate else 0, ws.data_ptr(),
+                                      ws.numel() * 4, _stream(a0)), "ldm_conv_wgrad")
+    return out
+
+
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(device, nbytes: int) -> torch.Tensor:
+    """Per-(device, stream) scratch for the pixel-split partial tiles of ldm_conv_wgrad; grows to the largest layer."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = _wgrad_ws[key] = torch.empty(max(nbytes // 4 + 1, 1 << 20), dtype=torch.float32, device=device)
+    return ws
+
+
 _launch_log = None
 
 _SPLITK_MAX_ROWS = 4096                 # only layers this small are ever offered the workspace

@@ -232,6 +232,51 @@ def test_split_k(tile, monkeypatch):
     assert y.dtype == torch.float32 and rel_l2(y, ref) < 2e-5 + 1e-3  # SiLU by v_exp/v_rcp: ~1e-6 relative
 
 
+# ---------------------------------------------------------------------------------------- backward
+def _wgrad_ref(x_nchw, dy_nchw, wshape, stride=1, upsample=False):
+    """torch autograd of F.conv2d on CPU float32 (inputs already rounded to bf16)."""
+    w = torch.zeros(wshape, requires_grad=True)
+    xin = F.interpolate(x_nchw, scale_factor=2.0, mode="nearest") if upsample else x_nchw
+    y = F.conv2d(xin, w, None, stride=stride, padding=wshape[-1] // 2)
+    y.backward(dy_nchw)
+    return w.grad
+
+
+@pytest.mark.parametrize("B,c0,c1,Cout,H,W,ks,stride,up", [
+    (2, 64, 0, 128, 16, 16, 3, 1, False), (3, 96, 32, 72, 9, 7, 3, 1, False), (1, 320, 0, 320, 12, 10, 3, 1, False),
+    (2, 64, 0, 64, 16, 16, 3, 2, False), (2, 64, 0, 40, 8, 8, 3, 1, True), (4, 128, 64, 136, 8, 8, 1, 1, False),
+    (33, 40, 0, 24, 8, 8, 3, 1, False)])
+def test_conv_wgrad(B, c0, c1, Cout, H, W, ks, stride, up):
+    """ldm_conv_wgrad against autograd of F.conv2d: 3x3 / 1x1, two sources, stride 2, upsample, ragged tiles, K-tiles
+    that straddle taps and the concat boundary, and enough pixels for several pixel splits."""
+    ops = _ops()
+    dt = torch.bfloat16
+    x, xr = _q(nhwc(seeded((B, c0, H, W), 1)), dt)
+    s_, sr = (_q(nhwc(seeded((B, c1, H, W), 2)), dt) if c1 else (None, None))
+    Ho = (H * (2 if up else 1) + 2 * (ks // 2) - ks) // stride + 1
+    Wo = (W * (2 if up else 1) + 2 * (ks // 2) - ks) // stride + 1
+    dy, dyr = _q(nhwc(seeded((B, Cout, Ho, Wo), 3)), dt)
+    dw = ops.conv_wgrad(x, dy, a1=s_, ksize=ks, stride=stride, upsample=up)
+    xin = xr if s_ is None else torch.cat([xr, sr], dim=-1)
+    ref = _wgrad_ref(xin.permute(0, 3, 1, 2), dyr.permute(0, 3, 1, 2), (Cout, c0 + c1, ks, ks), stride, up)
+    assert dw.numel() == ref.numel() and dw.dtype == torch.float32   # 1x1 matrices come back as [N, C]
+    dw = dw.reshape(ref.shape)
+    assert rel_l2(dw, ref) < 2e-5          # bf16 products are exact in fp32; only the summation order differs
+    acc = dw.clone().reshape(-1, c0 + c1) if ks == 1 else dw.clone()
+    dw2 = ops.conv_wgrad(x, dy, a1=s_, ksize=ks, stride=stride, upsample=up, out=acc)
+    assert rel_l2(dw2.reshape(ref.shape), 2 * ref) < 2e-5     # accumulate
+
+
+def test_linear_wgrad():
+    ops = _ops()
+    dt = torch.bfloat16
+    x, xr = _q(seeded((3, 700, 320), 1), dt)
+    dy, dyr = _q(seeded((3, 700, 200), 2), dt)
+    dw = ops.conv_wgrad(x, dy)
+    ref = dyr.reshape(-1, 200).t() @ xr.reshape(-1, 320)
+    assert dw.shape == (200, 320) and rel_l2(dw, ref) < 2e-5
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32
