@@ -115,7 +115,9 @@ typedef struct LdmConvGemm {
   int32_t hout, wout;          /* output spatial extent */
   int32_t ksize;               /* 1 or 3 (pad = ksize/2) */
   int32_t stride;              /* 1 or 2 (unet.py:218 downsample) */
-  int32_t upsample;            /* 1: nearest-2x before the conv (unet.py:316-317, :385-386) */
+  int32_t upsample;            /* 1: nearest-2x before the conv (unet.py:316-317, :385-386);
+                                * 2: zero-insertion 2x (only even positions hold data): with the 180-degree-rotated,
+                                *    in/out-transposed filter this is the input gradient of the stride-2 conv (:218) */
   /* B operand: packed filter [n][ksize*ksize*(c0+c1)] */
   const void* w;
   int32_t n;
@@ -174,6 +176,44 @@ int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c1, int dtyp
 /* Row-wise LayerNorm over the last dimension (unet.py:550-551, :576), eps 1e-5. */
 int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,
                   const float* beta, void* out, void* stream);
+
+/* ------------------------------------------------------------------ UNet: backward (HBM-bound kernels)
+ * What loss.backward() (train_latent_diffusion.py:1117) computes for the non-GEMM layers of ldm/unet.py.  All
+ * deterministic (fixed-order reductions); workspaces are caller-provided DEVICE scratch. */
+
+/* out[b][h][w][c] = sum of the 2x2 block of x at (2h, 2w) (+ residual): gradient of F.interpolate(scale_factor=2,
+ * mode="nearest") (unet.py:316, :385).  x: (batch, 2*hout, 2*wout, c) NHWC. */
+int ldm_sum2x2(const void* x, const void* residual, void* out, int dtype, int batch, int hout, int wout, int c, void* stream);
+
+/* out[s][n] (+)= sum_r x[s*rows_per_segment + r][n], float32: bias gradients (segments = 1 or summed by the caller) and
+ * the gradient of the per-sample time-embedding add (unet.py:727-728; segments = batch). */
+long long ldm_colsum_workspace_floats(long long segments, int n);
+int ldm_colsum(const void* x, int dtype, long long segments, long long rows_per_segment, int n, float* out, int accumulate,
+               float* workspace, void* stream);
+
+/* GEGLU / SwiGLU in training form (unet.py:787-790 / :765-768): h = packed-order pre-activation [rows][2*ff] (every 32
+ * columns = 16 values then their 16 gates, as ldm_pack_weight(glu_pairs) orders the projection); out[rows][ff] =
+ * value * act(gate); backward: dh from dout.  gelu != 0: exact GELU, else SiLU. */
+int ldm_glu_forward(const void* h, void* out, int dtype, long long rows, int ff, int gelu, void* stream);
+int ldm_glu_backward(const void* h, const void* dout, void* dh, int dtype, long long rows, int ff, int gelu, void* stream);
+
+/* dx = dy * d/dx silu(x)  (time-embedding MLP, unet.py:31, :703). */
+int ldm_silu_backward(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream);
+
+/* Backward of y = [SiLU](GroupNorm(x)) (unet.py:699-700, :705-706, :480, :113-114) on NHWC (two-source concat allowed):
+ * dx (+ add, an optional second gradient arriving at x) for all c0+c1 channels, dgamma / dbeta (float32, (+)= when
+ * accumulate).  stats: mean/rstd from ldm_groupnorm_stats.  dy, add, dx: [batch*hw][c0+c1] in dtype. */
+long long ldm_groupnorm_backward_workspace_floats(int batch, int channels, int groups);
+int ldm_groupnorm_backward(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups,
+                           const float* stats, const float* gamma, const float* beta, int silu, const void* dy,
+                           const void* add, void* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                           void* stream);
+
+/* Backward of nn.LayerNorm (unet.py:550-551, :576): statistics are recomputed from x. */
+long long ldm_layernorm_backward_workspace_floats(int cols);
+int ldm_layernorm_backward(const void* x, const void* dy, int dtype, long long rows, int cols, float eps, const float* gamma,
+                           const void* add, void* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
+                           void* stream);
 
 /* -------------------------------------------------------------------------------- UNet: attention */
 

@@ -186,7 +186,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
-        const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+        bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+        if (p.upsample == 2) ok = ok && ((ih | iw) & 1) == 0;   // zero insertion: only even positions hold data
         if (p.upsample) { ih >>= 1; iw >>= 1; }
         a_voff[it] = ok ? ((unsigned)(a_pix[it] + ih * p.win + iw) * cs + a_sw[it]) * 2u : OOB;
       }
@@ -615,7 +616,8 @@ conv_gemm_f32_kernel(const ConvGemmParams p) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       int ih = a_ih[it] + kh, iw = a_iw[it] + kw;
-      const bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+      bool ok = a_pix[it] >= 0 && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+      if (p.upsample == 2) ok = ok && ((ih | iw) & 1) == 0;
       if (p.upsample) { ih >>= 1; iw >>= 1; }
       va[it] = ok ? *reinterpret_cast<const float4*>(src + ((size_t)(a_pix[it] + ih * p.win + iw) * cs + cc + cq))
                   : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -793,14 +795,20 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   LDM_REQUIRE(d->out_dtype == d->dtype || d->out_dtype == LDM_F32, "ldm_conv_gemm: out_dtype must equal dtype or be float32");
   LDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "ldm_conv_gemm: ksize must be 1 or 3 (got %d)", d->ksize);
   LDM_REQUIRE(d->stride == 1 || d->stride == 2, "ldm_conv_gemm: stride must be 1 or 2 (got %d)", d->stride);
+  LDM_REQUIRE(d->upsample >= 0 && d->upsample <= 2, "ldm_conv_gemm: upsample must be 0, 1 (nearest) or 2 (zero insertion)");
   LDM_REQUIRE(!(d->upsample && d->stride != 1), "ldm_conv_gemm: upsample with stride 2 is not a thing");
   LDM_REQUIRE(d->batch >= 0 && d->hin >= 1 && d->win >= 1 && d->hout >= 1 && d->wout >= 1 && d->n >= 1 && d->c0 >= 1 && d->c1 >= 0,
               "ldm_conv_gemm: bad sizes");
   const int pad = d->ksize / 2;
   const int hsrc = d->upsample ? 2 * d->hin : d->hin, wsrc = d->upsample ? 2 * d->win : d->win;
-  LDM_REQUIRE(d->hout == (hsrc + 2 * pad - d->ksize) / d->stride + 1 && d->wout == (wsrc + 2 * pad - d->ksize) / d->stride + 1,
-              "ldm_conv_gemm: output extent %dx%d does not match input %dx%d (k=%d, stride=%d, upsample=%d)",
-              d->hout, d->wout, d->hin, d->win, d->ksize, d->stride, d->upsample);
+  {
+    const int he = (hsrc + 2 * pad - d->ksize) / d->stride + 1, we = (wsrc + 2 * pad - d->ksize) / d->stride + 1;
+    // zero insertion is the input gradient of a stride-2 conv, whose input may have had an odd extent (2*hin - 1)
+    const bool ok = d->upsample == 2 ? ((d->hout == he || d->hout == he - 1) && (d->wout == we || d->wout == we - 1))
+                                     : (d->hout == he && d->wout == we);
+    LDM_REQUIRE(ok, "ldm_conv_gemm: output extent %dx%d does not match input %dx%d (k=%d, stride=%d, upsample=%d)",
+                d->hout, d->wout, d->hin, d->win, d->ksize, d->stride, d->upsample);
+  }
   const long long M64 = (long long)d->batch * d->hout * d->wout;
   LDM_REQUIRE(M64 < (1LL << 31) && (long long)d->batch * d->hin * d->win < (1LL << 31), "ldm_conv_gemm: too many pixels");
   if (M64 == 0) return LDM_OK;

@@ -63,6 +63,15 @@ _SIGNATURES = {
     "ldm_conv_gemm": [C.POINTER(ConvGemmDesc), c_void_p],
     "ldm_conv_gemm_tile": [C.POINTER(ConvGemmDesc), C.POINTER(C.c_int)],
     "ldm_conv_wgrad": [C.POINTER(ConvGemmDesc), c_void_p, c_void_p, c_int, c_void_p, C.c_longlong, c_void_p],
+    "ldm_sum2x2": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "ldm_colsum": [c_void_p, c_int, C.c_longlong, C.c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
+    "ldm_glu_forward": [c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
+    "ldm_glu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
+    "ldm_silu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_void_p],
+    "ldm_groupnorm_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "ldm_layernorm_backward": [c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ldm_groupnorm_workspace_floats": [c_int, c_int],
     "ldm_groupnorm_stats": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
                             c_void_p, c_void_p],
@@ -79,7 +88,15 @@ _SIGNATURES = {
                      c_void_p],
 }
 
-EXPORTED_SYMBOLS = ["ldm_abi_version", "ldm_last_error", "ldm_conv_wgrad_workspace_bytes"] + list(_SIGNATURES)
+# host-only size queries returning long long
+_LONGLONG_QUERIES = {
+    "ldm_colsum_workspace_floats": [C.c_longlong, c_int],
+    "ldm_groupnorm_backward_workspace_floats": [c_int, c_int, c_int],
+    "ldm_layernorm_backward_workspace_floats": [c_int],
+}
+
+EXPORTED_SYMBOLS = (["ldm_abi_version", "ldm_last_error", "ldm_conv_wgrad_workspace_bytes"] + list(_SIGNATURES)
+                    + list(_LONGLONG_QUERIES))
 
 _lib = None
 
@@ -107,6 +124,10 @@ def load():
         fn.argtypes = argtypes
     lib.ldm_conv_wgrad_workspace_bytes.restype = C.c_longlong
     lib.ldm_conv_wgrad_workspace_bytes.argtypes = [C.POINTER(ConvGemmDesc)]
+    for name, argtypes in _LONGLONG_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_longlong
+        fn.argtypes = argtypes
     if lib.ldm_abi_version() != 1:
         raise LdmError(f"ABI version mismatch: library reports {lib.ldm_abi_version()}, binding expects 1")
     _lib = lib

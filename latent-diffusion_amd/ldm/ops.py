@@ -59,9 +59,10 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) ->
 def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
               upsample: bool = False, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, silu: bool = False, glu: Optional[str] = None,
-              out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+              out_dtype: Optional[torch.dtype] = None, out_hw=None) -> torch.Tensor:
     """Implicit-GEMM conv / linear.  a0 (and a1): (B, H, W, C) NHWC, or (..., C) matrices for ksize == 1.
-    w: packed [N, ksize*ksize*(C0+C1)].  Returns NHWC (B, Hout, Wout, N') / (..., N')."""
+    w: packed [N, ksize*ksize*(C0+C1)].  Returns NHWC (B, Hout, Wout, N') / (..., N').
+    upsample: False, True (nearest 2x, unet.py:316) or "zero" (zero-insertion 2x: input gradient of a stride-2 conv)."""
     _gpu(a0, a1, w, bias, rowvec, residual)
     if not a0.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
         raise ValueError("conv_gemm: activations must be contiguous NHWC")
@@ -84,6 +85,8 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
         pad = ksize // 2
         hout = (hs + 2 * pad - ksize) // stride + 1
         wout = (ws + 2 * pad - ksize) // stride + 1
+        if out_hw is not None:      # zero insertion: the forward input may have had an odd extent
+            hout, wout = out_hw
         out_lead = (batch, hout, wout)
     if a1 is not None and a1.shape[:-1] != a0.shape[:-1]:
         raise ValueError("conv_gemm: the two sources must agree in all but the channel dimension")
@@ -109,7 +112,7 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
     nout = n // 2 if glu else n
     out = torch.empty((*out_lead, nout), dtype=odt, device=a0.device)
     d = ConvGemmDesc(a0=a0.data_ptr(), a1=_ptr(a1), c0=c0, c1=c1, batch=batch, hin=hin, win=win, hout=hout, wout=wout,
-                     ksize=ksize, stride=stride, upsample=1 if upsample else 0, w=w.data_ptr(), n=n, epilogue=epi,
+                     ksize=ksize, stride=stride, upsample=(2 if upsample == "zero" else 1 if upsample else 0), w=w.data_ptr(), n=n, epilogue=epi,
                      bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
                      residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
     if a0.dtype == torch.bfloat16 and batch * hout * wout <= _SPLITK_MAX_ROWS:
@@ -129,6 +132,43 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
             _launch_log.append((f"conv_gemm_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel<{tile[0]},{tile[1]},{tile[2]}>",
                                 2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1,
                                 (m, n, ksize * ksize * (c0 + c1), ksize, stride, int(bool(upsample)), c1, epi)))
+    return out
+
+
+def pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Filter of the input-gradient pass: in/out transposed, taps rotated by 180 degrees, then packed K-contiguous
+    ([Cin][kh][kw][Cout]) -- so that dX = conv_gemm(dY, this) for a stride-1 conv / linear layer."""
+    if w.dim() == 4:
+        wd = w.detach().flip(2, 3).transpose(0, 1).contiguous()
+    else:
+        wd = w.detach().t().contiguous()
+    return pack_weight(wd, dtype)
+
+
+def conv_dgrad(dy: torch.Tensor, wd: torch.Tensor, *, ksize: int = 1, stride: int = 1, upsample: bool = False,
+               in_hw=None, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Input gradient of conv_gemm(x, w, ksize, stride, upsample) for all of x's channels (both sources of a concat:
+    slice the result).  wd = pack_weight_dgrad(w).  in_hw: spatial extent of x (needed for stride 2).  ``residual`` is
+    added to the result (gradient arriving over a skip path)."""
+    if ksize == 1 or (stride == 1 and not upsample):
+        return conv_gemm(dy, wd, ksize=ksize, residual=residual)
+    if stride == 2:
+        return conv_gemm(dy, wd, ksize=ksize, upsample="zero", out_hw=in_hw, residual=residual)
+    # nearest-2x upsample then conv: gradient at the upsampled extent, then fold every 2x2 block
+    du = conv_gemm(dy, wd, ksize=ksize)
+    return sum2x2(du, residual=residual)
+
+
+def sum2x2(x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b, h, w, c] = sum of the 2x2 block of x at (2h, 2w): gradient of nearest-2x upsampling (unet.py:316)."""
+    _gpu(x, residual)
+    B, H, W, Cc = x.shape
+    if H % 2 or W % 2 or Cc % 8 or not x.is_contiguous():
+        raise ValueError("sum2x2: contiguous (B, even H, even W, C % 8 == 0) input")
+    out = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_sum2x2(x.data_ptr(), _ptr(residual), out.data_ptr(), dt_code(x.dtype), B, H // 2, W // 2, Cc,
+                                          _stream(x)), "ldm_sum2x2")
     return out
 
 
@@ -244,6 +284,133 @@ def groupnorm(a0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
                                            gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, out.data_ptr(), st),
                    "ldm_groupnorm_apply")
     return out
+
+
+def groupnorm_with_stats(a0, gamma, beta, groups, *, a1=None, silu=False, eps=1e-5):
+    """groupnorm() that also returns the (B, groups, 2) mean/rstd tensor the backward needs."""
+    _gpu(a0, a1, gamma, beta)
+    B = a0.shape[0]
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    hw = a0.numel() // (B * c0) if B else 1
+    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=a0.device)
+    out = torch.empty((*a0.shape[:-1], c0 + c1), dtype=a0.dtype, device=a0.device)
+    lib = _lib.load()
+    code = dt_code(a0.dtype)
+    with torch.cuda.device(a0.device):
+        st = _stream(a0)
+        ws = _gn_workspace(a0.device, B, groups)
+        _lib.check(lib.ldm_groupnorm_stats(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, stats.data_ptr(),
+                                           ws.data_ptr(), st), "ldm_groupnorm_stats")
+        _lib.check(lib.ldm_groupnorm_apply(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, stats.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, out.data_ptr(), st),
+                   "ldm_groupnorm_apply")
+    return out, stats
+
+
+_bwd_ws = {}
+
+
+def _bwd_workspace(device, nfloats: int) -> torch.Tensor:
+    """Per-(device, stream) float32 scratch of the HBM-bound backward kernels; grows to the largest request."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _bwd_ws.get(key)
+    if ws is None or ws.numel() < nfloats:
+        ws = _bwd_ws[key] = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
+    return ws
+
+
+def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=False, add=None, dgamma=None, dbeta=None):
+    """Backward of groupnorm(a0, ..., a1=a1, silu=silu): returns (dx over all c0+c1 channels [+ add], dgamma, dbeta).
+    dgamma / dbeta given: accumulated into (float32)."""
+    _gpu(a0, a1, stats, gamma, beta, dy, add, dgamma, dbeta)
+    B = a0.shape[0]
+    c0 = a0.shape[-1]
+    c1 = 0 if a1 is None else a1.shape[-1]
+    hw = a0.numel() // (B * c0) if B else 1
+    if not dy.is_contiguous() or dy.shape[-1] != c0 + c1 or dy.dtype != a0.dtype:
+        raise ValueError("groupnorm_backward: dy must be contiguous (.., c0+c1) in the activation dtype")
+    accumulate = dgamma is not None
+    if not accumulate:
+        dgamma = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
+        dbeta = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
+    dx = torch.empty_like(dy)
+    lib = _lib.load()
+    with torch.cuda.device(a0.device):
+        ws = _bwd_workspace(a0.device, lib.ldm_groupnorm_backward_workspace_floats(B, c0 + c1, groups))
+        _lib.check(lib.ldm_groupnorm_backward(a0.data_ptr(), _ptr(a1), c0, c1, dt_code(a0.dtype), B, hw, groups, stats.data_ptr(),
+                                              gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, dy.data_ptr(), _ptr(add),
+                                              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate else 0,
+                                              ws.data_ptr(), _stream(a0)), "ldm_groupnorm_backward")
+    return dx, dgamma, dbeta
+
+
+def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None, dbeta=None):
+    """Backward of layernorm(x, gamma, beta): returns (dx [+ add], dgamma, dbeta)."""
+    _gpu(x, gamma, dy, add, dgamma, dbeta)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    accumulate = dgamma is not None
+    if not accumulate:
+        dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        ws = _bwd_workspace(x.device, lib.ldm_layernorm_backward_workspace_floats(cols))
+        _lib.check(lib.ldm_layernorm_backward(x.data_ptr(), dy.data_ptr(), dt_code(x.dtype), rows, cols, eps, gamma.data_ptr(),
+                                              _ptr(add), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                              1 if accumulate else 0, ws.data_ptr(), _stream(x)), "ldm_layernorm_backward")
+    return dx, dgamma, dbeta
+
+
+def colsum(x: torch.Tensor, segments: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 column sums per segment of consecutive rows: (segments, n).  out given: accumulated into."""
+    _gpu(x, out)
+    n = x.shape[-1]
+    rows = x.numel() // n
+    if rows % segments:
+        raise ValueError("colsum: rows not divisible by segments")
+    accumulate = out is not None
+    if out is None:
+        out = torch.empty((segments, n), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    with torch.cuda.device(x.device):
+        ws = _bwd_workspace(x.device, lib.ldm_colsum_workspace_floats(segments, n))
+        _lib.check(lib.ldm_colsum(x.data_ptr(), dt_code(x.dtype), segments, rows // segments, n, out.data_ptr(),
+                                  1 if accumulate else 0, ws.data_ptr(), _stream(x)), "ldm_colsum")
+    return out
+
+
+def glu_forward(h: torch.Tensor, act: str) -> torch.Tensor:
+    """Training form of GEGLU / SwiGLU: h = packed-order pre-activation (.., 2*ff) -> (.., ff)."""
+    _gpu(h)
+    ff = h.shape[-1] // 2
+    out = torch.empty((*h.shape[:-1], ff), dtype=h.dtype, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().ldm_glu_forward(h.data_ptr(), out.data_ptr(), dt_code(h.dtype), h.numel() // (2 * ff), ff,
+                                               1 if act == "geglu" else 0, _stream(h)), "ldm_glu_forward")
+    return out
+
+
+def glu_backward(h: torch.Tensor, dout: torch.Tensor, act: str) -> torch.Tensor:
+    _gpu(h, dout)
+    ff = h.shape[-1] // 2
+    dh = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        _lib.check(_lib.load().ldm_glu_backward(h.data_ptr(), dout.data_ptr(), dh.data_ptr(), dt_code(h.dtype),
+                                                h.numel() // (2 * ff), ff, 1 if act == "geglu" else 0, _stream(h)),
+                   "ldm_glu_backward")
+    return dh
+
+
+def silu_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    _gpu(x, dy)
+    dx = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_silu_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dt_code(x.dtype), x.numel(),
+                                                 _stream(x)), "ldm_silu_backward")
+    return dx
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:

@@ -277,6 +277,113 @@ def test_linear_wgrad():
     assert dw.shape == (200, 320) and rel_l2(dw, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks,stride,up", [
+    (2, 64, 128, 16, 16, 3, 1, False), (1, 96, 32, 9, 7, 3, 1, False), (2, 64, 96, 16, 16, 3, 2, False),
+    (1, 32, 64, 7, 9, 3, 2, False), (2, 64, 32, 8, 8, 3, 1, True), (3, 128, 96, 5, 6, 1, 1, False)])
+def test_conv_dgrad(B, Cin, Cout, H, W, ks, stride, up):
+    """Input gradient through the forward kernel with the transposed / rotated filter: stride 1, stride 2 (zero
+    insertion, odd extents) and nearest-upsample (2x2 fold)."""
+    ops = _ops()
+    dt = torch.bfloat16
+    w = seeded((Cout, Cin, ks, ks), 2) / math.sqrt(ks * ks * Cin)
+    x = seeded((B, Cin, H, W), 1).to(dt).float().requires_grad_(True)
+    wq = w.to(dt).float()
+    y = _conv_ref(x, wq, None, stride, up)
+    dyr = seeded(tuple(y.shape), 3).to(dt).float()
+    y.backward(dyr)
+    wd = ops.pack_weight_dgrad(w.cuda(), dt)
+    dx = ops.conv_dgrad(nhwc(dyr).to(dt).cuda(), wd, ksize=ks, stride=stride, upsample=up, in_hw=(H, W))
+    assert dx.shape == (B, H, W, Cin)
+    assert rel_l2(dx, nhwc(x.grad)) < TOL[dt]
+
+
+def test_colsum_and_sum2x2():
+    ops = _ops()
+    for dt in DTYPES:
+        x, xr = _q(seeded((6, 700, 328), 1), dt)
+        assert rel_l2(ops.colsum(x, 6), xr.sum(1)) < 2e-6
+        assert rel_l2(ops.colsum(x, 1), xr.sum((0, 1))[None]) < 2e-6
+        acc = ops.colsum(x, 6)
+        ops.colsum(x, 6, out=acc)
+        assert rel_l2(acc, 2 * xr.sum(1)) < 2e-6
+        u, ur = _q(seeded((2, 6, 10, 40), 2), dt)
+        r, rr = _q(seeded((2, 3, 5, 40), 3), dt)
+        ref = ur.reshape(2, 3, 2, 5, 2, 40).sum((2, 4)) + rr
+        assert rel_l2(ops.sum2x2(u, residual=r), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["geglu", "swiglu"])
+def test_glu_training_form(dtype, act):
+    """glu_forward on the packed-order pre-activation equals the fused epilogue's result; glu_backward vs autograd."""
+    ops = _ops()
+    M, ff = 150, 64
+    hr = seeded((M, 2 * ff), 1).to(dtype).float()       # checkpoint order: [value | gate]
+    blocks = hr.reshape(M, 2, ff // 16, 16).permute(0, 2, 1, 3).reshape(M, 2 * ff)   # packed order
+    h = blocks.to(dtype).cuda()
+    hv = hr.clone().requires_grad_(True)
+    val, gate = hv.chunk(2, dim=-1)
+    out_ref = val * (F.gelu(gate) if act == "geglu" else F.silu(gate))
+    out = ops.glu_forward(h, act)
+    assert rel_l2(out, out_ref.detach()) < TOL[dtype]
+    dor = seeded((M, ff), 2).to(dtype).float()
+    out_ref.backward(dor)
+    dh = ops.glu_backward(h, dor.to(dtype).cuda(), act)
+    dref = hv.grad.reshape(M, 2, ff // 16, 16).permute(0, 2, 1, 3).reshape(M, 2 * ff)
+    assert rel_l2(dh, dref) < TOL[dtype]
+    xs, xsr = _q(seeded((1000,), 3), dtype)
+    xg = xsr.clone().requires_grad_(True)
+    F.silu(xg).backward(dor.flatten()[:1000])
+    assert rel_l2(ops.silu_backward(xs, dor.flatten()[:1000].to(dtype).cuda()), xg.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,c0,c1,H,W,silu", [(2, 320, 0, 16, 16, True), (3, 64, 32, 5, 7, True), (1, 1280, 1280, 8, 8, True),
+                                               (2, 64, 0, 12, 12, False)])
+def test_groupnorm_backward(dtype, B, c0, c1, H, W, silu):
+    ops = _ops()
+    C = c0 + c1
+    x0, x0r = _q(seeded((B, H, W, c0), 1), dtype)
+    x1, x1r = (_q(seeded((B, H, W, c1), 2), dtype) if c1 else (None, None))
+    gamma = 1.0 + 0.1 * seeded((C,), 3)
+    beta = 0.1 * seeded((C,), 4)
+    dy, dyr = _q(seeded((B, H, W, C), 5), dtype)
+    add, addr = _q(seeded((B, H, W, C), 6), dtype)
+    xr = (x0r if c1 == 0 else torch.cat([x0r, x1r], -1)).clone().requires_grad_(True)
+    g = gamma.clone().requires_grad_(True)
+    b = beta.clone().requires_grad_(True)
+    y = F.group_norm(xr.permute(0, 3, 1, 2), 32, g, b, 1e-5)
+    if silu:
+        y = F.silu(y)
+    y.backward(dyr.permute(0, 3, 1, 2))
+    _, stats = ops.groupnorm_with_stats(x0, gamma.cuda(), beta.cuda(), 32, a1=x1, silu=silu)
+    dx, dg, db = ops.groupnorm_backward(x0, stats, gamma.cuda(), beta.cuda(), 32, dy, a1=x1, silu=silu, add=add)
+    tol = 3 * TOL[dtype] if dtype == torch.bfloat16 else 2e-5
+    assert rel_l2(dx, xr.grad + addr) < tol
+    assert rel_l2(dg, g.grad) < 2e-5 + (1e-3 if dtype == torch.bfloat16 else 0)
+    assert rel_l2(db, b.grad) < 2e-5 + (1e-3 if dtype == torch.bfloat16 else 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(300, 320), (5000, 640), (77, 1280), (3, 64)])
+def test_layernorm_backward(dtype, rows, cols):
+    ops = _ops()
+    x, xr = _q(seeded((rows, cols), 1), dtype)
+    gamma = 1.0 + 0.1 * seeded((cols,), 2)
+    beta = 0.1 * seeded((cols,), 3)
+    dy, dyr = _q(seeded((rows, cols), 4), dtype)
+    xg = xr.clone().requires_grad_(True)
+    g = gamma.clone().requires_grad_(True)
+    b = beta.clone().requires_grad_(True)
+    F.layer_norm(xg, (cols,), g, b, 1e-5).backward(dyr)
+    dx, dg, db = ops.layernorm_backward(x, gamma.cuda(), dy)
+    assert rel_l2(dx, xg.grad) < (2 * TOL[dtype] if dtype == torch.bfloat16 else 2e-5)
+    assert rel_l2(dg, g.grad) < 2e-5 and rel_l2(db, b.grad) < 2e-5
+    dg2, db2 = dg.clone(), db.clone()
+    ops.layernorm_backward(x, gamma.cuda(), dy, dgamma=dg2, dbeta=db2)
+    assert rel_l2(dg2, 2 * g.grad) < 2e-5
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32
