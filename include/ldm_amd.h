@@ -223,6 +223,20 @@ int ldm_layernorm_backward(const void* x, const void* dy, int dtype, long long r
 int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
                   int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, void* stream);
 
+/* Training form: also writes lse[batch][heads][lq] (float32) = log2 sum_k exp2(log2(e)/sqrt(d) * q.k), which the
+ * backward needs to recompute the probabilities. */
+int ldm_attention_train(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                        int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, float* lse, void* stream);
+
+/* Backward of F.scaled_dot_product_attention (unet.py:678): dq, dk, dv from q, k, v, the forward output o, its
+ * gradient d_o and lse.  Flash-style (the score matrix is recomputed tile by tile, never stored), two deterministic
+ * kernels (no atomics).  All tensors (rows, heads*d) with the given row strides, head h in columns [h*d, (h+1)*d);
+ * dk and dv share dkv_stride.  delta_workspace: batch*heads*lq floats.  bf16, head dims 40/64/80/128/160. */
+int ldm_attention_backward(const void* q, int q_stride, const void* k, const void* v, int kv_stride, const void* o,
+                           int o_stride, const void* d_o, int do_stride, const float* lse, void* dq, int dq_stride,
+                           void* dk, void* dv, int dkv_stride, float* delta_workspace, int dtype, int batch, int heads,
+                           int lq, int lk, int d, void* stream);
+
 /* ------------------------------------------------------------------------ UNet: first / last layers */
 
 /* Sinusoidal timestep embedding, cos first, divisor dim/2-1 (unet.py:171-173 ->

@@ -33,6 +33,7 @@ struct AttnParams {
   int batch, heads, lq, lk;
   float scale_log2e;  // (1/sqrt(d)) * log2(e)
   float scale;
+  float* lse;         // optional [batch][heads][lq]: log2-sum-exp2 of the scaled scores (training: saved for the backward)
 #ifdef LDM_GEMM_STAMPS
   unsigned long long* stamps;  // diagnostic build only (make stamps): 16 cycle stamps per workgroup
 #endif
@@ -348,6 +349,7 @@ attention_bf16_kernel(const AttnParams p) {
     const float inv = 1.0f / l;
     const int qi = q0 + g * 16 + fr;
     if (qi >= p.lq) continue;
+    if (p.lse != nullptr && fq == 0) p.lse[((size_t)b * p.heads + h) * p.lq + qi] = m_run[g] + __log2f(l);
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
       const int col = dt * 16 + fq * 4;
@@ -432,6 +434,8 @@ attention_generic_kernel(const AttnParams p, int d) {
 #pragma unroll
   for (int qq = 0; qq < GEN_QPW; ++qq) {
     if (q0 + qq >= p.lq) continue;
+    if (p.lse != nullptr && lane == 0)
+      p.lse[((size_t)b * p.heads + h) * p.lq + q0 + qq] = (m_run[qq] + logf(l_run[qq])) * 1.4426950408889634f;
     const float inv = 1.0f / l_run[qq];
 #pragma unroll
     for (int k = 0; k < DPL; ++k) {
@@ -472,8 +476,23 @@ extern "C" int ldm_debug_set_attention_stamps(unsigned long long* buf, long long
 }
 #endif
 
+static int attention_impl(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                          int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, float* lse, void* stream);
+
 extern "C" int ldm_attention(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
                              int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, void* stream) {
+  return attention_impl(q, q_stride, k, v, kv_stride, out, out_stride, dtype, batch, heads, lq, lk, d, nullptr, stream);
+}
+
+extern "C" int ldm_attention_train(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                                   int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, float* lse,
+                                   void* stream) {
+  LDM_REQUIRE(lse != nullptr || batch == 0 || lq == 0, "ldm_attention_train: null lse");
+  return attention_impl(q, q_stride, k, v, kv_stride, out, out_stride, dtype, batch, heads, lq, lk, d, lse, stream);
+}
+
+static int attention_impl(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out,
+                          int out_stride, int dtype, int batch, int heads, int lq, int lk, int d, float* lse, void* stream) {
   LDM_REQUIRE(dtype_ok(dtype), "ldm_attention: bad dtype %d", dtype);
   LDM_REQUIRE(batch >= 0 && heads >= 1 && lq >= 0 && lk >= 1 && d >= 1, "ldm_attention: bad sizes");
   if (batch == 0 || lq == 0) return LDM_OK;
@@ -486,6 +505,7 @@ extern "C" int ldm_attention(const void* q, int q_stride, const void* k, const v
   p.batch = batch; p.heads = heads; p.lq = lq; p.lk = lk;
   p.scale = 1.0f / sqrtf((float)d);
   p.scale_log2e = p.scale * 1.4426950408889634f;
+  p.lse = lse;
 #ifdef LDM_GEMM_STAMPS
   p.stamps = (long long)((lq + 127) / 128) * heads * batch <= g_att_stamp_blocks ? g_att_stamp_buf : nullptr;
 #endif

@@ -1,0 +1,455 @@
+// Backward of the flash-style attention (no mask, scale 1/sqrt(d)), bf16 on v_mfma_f32_16x16x32_bf16.
+//
+// With c = log2(e)/sqrt(d), L[q] = log2 sum_k exp2(c s[q][k]) saved by the forward (ldm_attention_train) and
+// Dl[q] = sum_j dO[q][j] O[q][j]:
+//     P = exp2(c S - L),   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - Dl) / sqrt(d),   dQ = dS K,   dK = dS^T Q.
+// No atomics (deterministic): two kernels recompute S and dP.
+//   * attn_bwd_dq_kernel: a workgroup owns 128 queries (a wave 32, as two 16-query groups) and sweeps the keys in tiles
+//     of 64 -- the forward kernel's shape.  Transposed orientation: S^T = K Q^T and dP^T = V dO^T give every lane one
+//     query column, so L and Dl are per-lane scalars, and dS^T packed to bf16 is directly the B operand of
+//     dQ^T += K^T dS^T (K^T fragments by transposed LDS reads of the same K image).
+//   * attn_bwd_dkv_kernel: the mirror image.  A workgroup owns 128 keys (a wave 32) whose K and V fragments stay in
+//     registers as B operands, and sweeps the queries in tiles of 64 staged in LDS (Q and dO images, L and Dl vectors):
+//     S = Q K^T and dP = dO V^T give every lane one key column; P and dS packed to bf16 are the B operands of
+//     dV^T += dO^T P and dK^T += Q^T dS (Q^T / dO^T by transposed reads).
+// One LDS image per operand serves both the row reads (ds_read_b128, contraction over d) and the transposed reads
+// (ds_read_b64_tr_b16, contraction over rows): row pitch 2*DK + 16 bytes.
+#include "common.h"
+
+namespace ldm {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ uint32_t ab_cvt_pk_bf16(float a, float b) { return pack_bf16x2(a, b); }
+
+struct AttnBwdParams {
+  const void* q; const void* k; const void* v; const void* o; const void* d_o;
+  void* dq; void* dk; void* dv;
+  int q_stride, kv_stride, o_stride, do_stride, dq_stride, dkv_stride;
+  int batch, heads, lq, lk;
+  float scale_log2e, scale;
+  const float* lse;    // [batch][heads][lq]
+  float* delta;        // [batch][heads][lq]  (written by the prep kernel)
+};
+
+template <int D>
+struct AbGeom {
+  static constexpr int KS = (D + 31) / 32;
+  static constexpr int DK = KS * 32;
+  static constexpr int DT = (D + 15) / 16;
+  static constexpr int ROW = DK * 2 + 16;            // bytes per image row
+  static constexpr int IMG = 64 * ROW;               // one 64-row image
+  static constexpr int CPR = D / 8;
+  static constexpr int NCH = (64 * CPR + 255) / 256;
+  static constexpr int NBUF = D <= 80 ? 2 : 1;       // double-buffered tiles when they fit comfortably
+};
+
+__device__ __forceinline__ uint4 ab_buffer_load16(const void* base, unsigned bytes, unsigned voff, unsigned soff) {
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+// Dl[b][h][q] = sum_j dO[q][h*d + j] * O[q][h*d + j]; one wave per (b, h, q) row
+__global__ void __launch_bounds__(256)
+attn_bwd_prep_kernel(const AttnBwdParams p, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // over batch*heads*lq
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)p.batch * p.heads * p.lq) return;
+  const int qi = (int)(row % p.lq);
+  const long long bh = row / p.lq;
+  const int h = (int)(bh % p.heads);
+  const long long b = bh / p.heads;
+  const bf16_t* o = static_cast<const bf16_t*>(p.o) + (b * p.lq + qi) * p.o_stride + h * d;
+  const bf16_t* g = static_cast<const bf16_t*>(p.d_o) + (b * p.lq + qi) * p.do_stride + h * d;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) s += bf16_to_f32(o[j]) * bf16_to_f32(g[j]);
+  s = wave_sum(s);
+  if (lane == 0) p.delta[row] = s;
+}
+
+// Stage a 64-row tile of one operand (rows row0.., head slice of D columns) into registers / commit to an LDS image.
+template <int D>
+struct TileStager {
+  using G = AbGeom<D>;
+  unsigned g_off[G::NCH];
+  int l_off[G::NCH];
+  __device__ __forceinline__ void init(int tid, int stride) {
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) {
+      const int idx = c * 256 + tid;
+      const int row = idx / G::CPR, ch = idx - row * G::CPR;
+      const bool ok = idx < 64 * G::CPR;
+      g_off[c] = ok ? ((unsigned)row * stride + ch * 8) * 2u : 0x80000000u;
+      l_off[c] = ok ? row * G::ROW + ch * 16 : -1;
+    }
+  }
+  __device__ __forceinline__ void fetch(const void* base, unsigned bytes, unsigned soff, uint4 (&r)[G::NCH]) const {
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c) r[c] = ab_buffer_load16(base, bytes, g_off[c], soff);
+  }
+  __device__ __forceinline__ void commit(unsigned char* img, const uint4 (&r)[G::NCH]) const {
+#pragma unroll
+    for (int c = 0; c < G::NCH; ++c)
+      if (l_off[c] >= 0) *reinterpret_cast<uint4*>(img + l_off[c]) = r[c];
+  }
+};
+
+// fragments of a 64-row image
+template <int D>
+__device__ __forceinline__ bf16x8_t ab_row_frag(const unsigned char* img, int rb, int ks, int fr, int fq) {
+  return *reinterpret_cast<const bf16x8_t*>(img + (rb * 16 + fr) * AbGeom<D>::ROW + (ks * 4 + fq) * 16);
+}
+template <int D>
+__device__ __forceinline__ bf16x8_t ab_tr_frag(const unsigned char* img, int dt, int st, int fr, int fq) {
+  const int tq = fr >> 2, tp = fr & 3;
+  const unsigned char* a0 = img + ((2 * st) * 16 + 4 * fq + tq) * AbGeom<D>::ROW + (dt * 16 + 4 * tp) * 2;
+  const unsigned char* a1 = a0 + 16 * AbGeom<D>::ROW;
+  const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)a0);
+  const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)a1);
+  return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// four accumulator tiles (contraction rows kb = 0..3, 4 values each) -> two B operands (st = 0, 1)
+__device__ __forceinline__ void ab_pack(const float (&v)[4][4], bf16x8_t (&pb)[2]) {
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    u4 w;
+    w[0] = ab_cvt_pk_bf16(v[2 * st][0], v[2 * st][1]);
+    w[1] = ab_cvt_pk_bf16(v[2 * st][2], v[2 * st][3]);
+    w[2] = ab_cvt_pk_bf16(v[2 * st + 1][0], v[2 * st + 1][1]);
+    w[3] = ab_cvt_pk_bf16(v[2 * st + 1][2], v[2 * st + 1][3]);
+    pb[st] = __builtin_bit_cast(bf16x8_t, w);
+  }
+}
+
+// B-operand fragments of 16 rows held in registers: lane (row fr, k-group fq) holds X[row][32*ks + 8*fq + 0..7]
+template <int D>
+__device__ __forceinline__ void ab_load_bfrag(const bf16_t* base, int row, int nrows, int stride, int fq, bf16x8_t (&f)[AbGeom<D>::KS]) {
+#pragma unroll
+  for (int ks = 0; ks < AbGeom<D>::KS; ++ks) {
+    const int col = ks * 32 + fq * 8;
+    bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < nrows && col < D) z = *reinterpret_cast<const bf16x8_t*>(base + (size_t)row * stride + col);
+    f[ks] = z;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+template <int D>
+__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
+attn_bwd_dq_kernel(const AttnBwdParams p) {
+  using G = AbGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x (K image, V image)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
+  const bf16_t* gp = static_cast<const bf16_t*>(p.d_o) + (size_t)b * p.lq * p.do_stride + h * D;
+  const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
+  const bf16_t* vp = static_cast<const bf16_t*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * D;
+  bf16_t* dqp = static_cast<bf16_t*>(p.dq) + (size_t)b * p.lq * p.dq_stride + h * D;
+  const unsigned kv_bytes = ((unsigned)(p.lk - 1) * p.kv_stride + D) * 2u;
+
+  for (int i = tid * 16; i < G::NBUF * 2 * G::IMG; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  bf16x8_t qf[2][G::KS], gf[2][G::KS];
+  float Lq[2], Dq[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int qi = q0 + g * 16 + fr;
+    ab_load_bfrag<D>(qp, qi, p.lq, p.q_stride, fq, qf[g]);
+    ab_load_bfrag<D>(gp, qi, p.lq, p.do_stride, fq, gf[g]);
+    const bool ok = qi < p.lq;
+    Lq[g] = ok ? p.lse[((size_t)b * p.heads + h) * p.lq + qi] : INFINITY;   // invalid queries: P = 0
+    Dq[g] = ok ? p.delta[((size_t)b * p.heads + h) * p.lq + qi] : 0.f;
+  }
+  f32x4_t acc[2][G::DT];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) acc[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  TileStager<D> stg;
+  stg.init(tid, p.kv_stride);
+  uint4 kreg[G::NCH], vreg[G::NCH];
+  const int ntiles = (p.lk + 63) / 64;
+  auto fetch = [&](int t) {
+    const unsigned soff = (unsigned)t * 64u * p.kv_stride * 2u;
+    stg.fetch(kp, kv_bytes, soff, kreg);
+    stg.fetch(vp, kv_bytes, soff, vreg);
+  };
+  __syncthreads();
+  fetch(0);
+  stg.commit(smem, kreg);
+  stg.commit(smem + G::IMG, vreg);
+  if (ntiles > 1) fetch(1);
+  for (int t = 0; t < ntiles; ++t) {
+    unsigned char* cur = smem + (G::NBUF == 2 ? (t & 1) : 0) * 2 * G::IMG;
+    __syncthreads();
+    if (G::NBUF == 2 && t + 1 < ntiles) {
+      unsigned char* nxt = smem + ((t + 1) & 1) * 2 * G::IMG;
+      stg.commit(nxt, kreg);
+      stg.commit(nxt + G::IMG, vreg);
+      if (t + 2 < ntiles) fetch(t + 2);
+    }
+    const unsigned char* kimg = cur;
+    const unsigned char* vimg = cur + G::IMG;
+    const int t0 = t * 64;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      f32x4_t s[4], dp[4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        s[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(kimg, kb, ks, fr, fq), qf[g][ks], s[kb], 0, 0, 0);
+          dp[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(vimg, kb, ks, fr, fq), gf[g][ks], dp[kb], 0, 0, 0);
+        }
+      }
+      float ds[4][4];
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = t0 + kb * 16 + fq * 4 + r < p.lk;
+          const float pr = valid ? __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -Lq[g])) : 0.f;
+          ds[kb][r] = pr * (dp[kb][r] - Dq[g]) * p.scale;
+        }
+      bf16x8_t pb[2];
+      ab_pack(ds, pb);
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+          acc[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_tr_frag<D>(kimg, dt, st, fr, fq), pb[st], acc[g][dt], 0, 0, 0);
+    }
+    if (G::NBUF == 1 && t + 1 < ntiles) {
+      __syncthreads();
+      stg.commit(smem, kreg);
+      stg.commit(smem + G::IMG, vreg);
+      if (t + 2 < ntiles) fetch(t + 2);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int qi = q0 + g * 16 + fr;
+    if (qi >= p.lq) continue;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) {
+      const int col = dt * 16 + fq * 4;
+      if (col < D) {
+        uint2 w;
+        w.x = ab_cvt_pk_bf16(acc[g][dt][0], acc[g][dt][1]);
+        w.y = ab_cvt_pk_bf16(acc[g][dt][2], acc[g][dt][3]);
+        *reinterpret_cast<uint2*>(dqp + (size_t)qi * p.dq_stride + col) = w;
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------- dK, dV
+template <int D>
+__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
+attn_bwd_dkv_kernel(const AttnBwdParams p) {
+  using G = AbGeom<D>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x (Q image, dO image, L[64], Dl[64])
+  constexpr int BUF = 2 * G::IMG + 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
+  const bf16_t* gp = static_cast<const bf16_t*>(p.d_o) + (size_t)b * p.lq * p.do_stride + h * D;
+  const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
+  const bf16_t* vp = static_cast<const bf16_t*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * D;
+  bf16_t* dkp = static_cast<bf16_t*>(p.dk) + (size_t)b * p.lk * p.dkv_stride + h * D;
+  bf16_t* dvp = static_cast<bf16_t*>(p.dv) + (size_t)b * p.lk * p.dkv_stride + h * D;
+  const float* lsep = p.lse + ((size_t)b * p.heads + h) * p.lq;
+  const float* dlp = p.delta + ((size_t)b * p.heads + h) * p.lq;
+  const unsigned q_bytes = ((unsigned)(p.lq - 1) * p.q_stride + D) * 2u;
+  const unsigned g_bytes = ((unsigned)(p.lq - 1) * p.do_stride + D) * 2u;
+
+  for (int i = tid * 16; i < G::NBUF * BUF; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  bf16x8_t kf[2][G::KS], vf[2][G::KS];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int ki = k0 + g * 16 + fr;
+    ab_load_bfrag<D>(kp, ki, p.lk, p.kv_stride, fq, kf[g]);
+    ab_load_bfrag<D>(vp, ki, p.lk, p.kv_stride, fq, vf[g]);
+  }
+  f32x4_t dk[2][G::DT], dv[2][G::DT];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int t = 0; t < G::DT; ++t) { dk[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+
+  TileStager<D> sq, sg;
+  sq.init(tid, p.q_stride);
+  sg.init(tid, p.do_stride);
+  uint4 qreg[G::NCH], greg[G::NCH];
+  float lreg = 0.f, dreg = 0.f;      // threads 0..63 carry L / Dl of the tile's 64 queries
+  const int ntiles = (p.lq + 63) / 64;
+  auto fetch = [&](int t) {
+    sq.fetch(qp, q_bytes, (unsigned)t * 64u * p.q_stride * 2u, qreg);
+    sg.fetch(gp, g_bytes, (unsigned)t * 64u * p.do_stride * 2u, greg);
+    if (tid < 64) {
+      const int qi = t * 64 + tid;
+      lreg = qi < p.lq ? lsep[qi] : INFINITY;     // queries past lq: P = 0
+      dreg = qi < p.lq ? dlp[qi] : 0.f;
+    }
+  };
+  auto commit = [&](unsigned char* buf) {
+    sq.commit(buf, qreg);
+    sg.commit(buf + G::IMG, greg);
+    if (tid < 64) {
+      reinterpret_cast<float*>(buf + 2 * G::IMG)[tid] = lreg;
+      reinterpret_cast<float*>(buf + 2 * G::IMG + 256)[tid] = dreg;
+    }
+  };
+  __syncthreads();
+  fetch(0);
+  commit(smem);
+  if (ntiles > 1) fetch(1);
+  for (int t = 0; t < ntiles; ++t) {
+    unsigned char* cur = smem + (G::NBUF == 2 ? (t & 1) : 0) * BUF;
+    __syncthreads();
+    if (G::NBUF == 2 && t + 1 < ntiles) {
+      commit(smem + ((t + 1) & 1) * BUF);
+      if (t + 2 < ntiles) fetch(t + 2);
+    }
+    const unsigned char* qimg = cur;
+    const unsigned char* gimg = cur + G::IMG;
+    const float* lt = reinterpret_cast<const float*>(cur + 2 * G::IMG);
+    const float* dlt = reinterpret_cast<const float*>(cur + 2 * G::IMG + 256);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      // S[query rows qb*16 + fq*4 + r][key column fr] and dP alike
+      float pv[4][4], ds[4][4];
+#pragma unroll
+      for (int qb = 0; qb < 4; ++qb) {
+        f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < G::KS; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(qimg, qb, ks, fr, fq), kf[g][ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(gimg, qb, ks, fr, fq), vf[g][ks], dp, 0, 0, 0);
+        }
+        const float4 l4 = *reinterpret_cast<const float4*>(lt + qb * 16 + fq * 4);
+        const float4 d4 = *reinterpret_cast<const float4*>(dlt + qb * 16 + fq * 4);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lv[r]));
+          pv[qb][r] = pr;
+          ds[qb][r] = pr * (dp[r] - dl[r]) * p.scale;
+        }
+      }
+      bf16x8_t pbp[2], pbs[2];
+      ab_pack(pv, pbp);
+      ab_pack(ds, pbs);
+#pragma unroll
+      for (int dt = 0; dt < G::DT; ++dt)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          dv[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_tr_frag<D>(gimg, dt, st, fr, fq), pbp[st], dv[g][dt], 0, 0, 0);
+          dk[g][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_tr_frag<D>(qimg, dt, st, fr, fq), pbs[st], dk[g][dt], 0, 0, 0);
+        }
+    }
+    if (G::NBUF == 1 && t + 1 < ntiles) {
+      __syncthreads();
+      commit(smem);
+      if (t + 2 < ntiles) fetch(t + 2);
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int ki = k0 + g * 16 + fr;
+    if (ki >= p.lk) continue;
+#pragma unroll
+    for (int dt = 0; dt < G::DT; ++dt) {
+      const int col = dt * 16 + fq * 4;
+      if (col < D) {
+        uint2 w;
+        w.x = ab_cvt_pk_bf16(dk[g][dt][0], dk[g][dt][1]);
+        w.y = ab_cvt_pk_bf16(dk[g][dt][2], dk[g][dt][3]);
+        *reinterpret_cast<uint2*>(dkp + (size_t)ki * p.dkv_stride + col) = w;
+        w.x = ab_cvt_pk_bf16(dv[g][dt][0], dv[g][dt][1]);
+        w.y = ab_cvt_pk_bf16(dv[g][dt][2], dv[g][dt][3]);
+        *reinterpret_cast<uint2*>(dvp + (size_t)ki * p.dkv_stride + col) = w;
+      }
+    }
+  }
+}
+
+template <int D>
+static int launch_attn_bwd(const AttnBwdParams& p, hipStream_t st) {
+  using G = AbGeom<D>;
+  const int smem_dq = G::NBUF * 2 * G::IMG;
+  const int smem_dkv = G::NBUF * (2 * G::IMG + 512);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dq);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, smem_dkv);
+    if (e != hipSuccess) { set_error("ldm_attention_backward: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+    attr_done = true;
+  }
+  const long long rows = (long long)p.batch * p.heads * p.lq;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, D);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(prep)");
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3((p.lq + 127) / 128, p.heads, p.batch), dim3(256), smem_dq, st, p);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dq)");
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((p.lk + 127) / 128, p.heads, p.batch), dim3(256), smem_dkv, st, p);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dkv)");
+  return LDM_OK;
+}
+
+}  // namespace ldm
+
+using namespace ldm;
+
+extern "C" int ldm_attention_backward(const void* q, int q_stride, const void* k, const void* v, int kv_stride, const void* o,
+                                      int o_stride, const void* d_o, int do_stride, const float* lse, void* dq, int dq_stride,
+                                      void* dk, void* dv, int dkv_stride, float* delta_workspace, int dtype, int batch,
+                                      int heads, int lq, int lk, int d, void* stream) {
+  LDM_REQUIRE(dtype == LDM_BF16, "ldm_attention_backward: only the bf16 path is built (dtype %d)", dtype);
+  LDM_REQUIRE(batch >= 0 && heads >= 1 && lq >= 0 && lk >= 1 && d >= 1, "ldm_attention_backward: bad sizes");
+  if (batch == 0 || lq == 0) return LDM_OK;
+  LDM_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv && delta_workspace, "ldm_attention_backward: null pointer");
+  const int hd = heads * d;
+  LDM_REQUIRE(q_stride >= hd && kv_stride >= hd && o_stride >= hd && do_stride >= hd && dq_stride >= hd && dkv_stride >= hd,
+              "ldm_attention_backward: row strides smaller than heads*d");
+  LDM_REQUIRE(batch <= 65535 && heads <= 65535, "ldm_attention_backward: batch/heads exceed the grid limits");
+  LDM_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_o) && q_stride % 8 == 0 && kv_stride % 8 == 0 &&
+                  do_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 &&
+                  (reinterpret_cast<uintptr_t>(dv) & 7) == 0 && dq_stride % 4 == 0 && dkv_stride % 4 == 0,
+              "ldm_attention_backward: operands must be 16-byte aligned with strides in multiples of 8 elements");
+  LDM_REQUIRE((long long)lk * kv_stride * 2 < (1LL << 31) && (long long)lq * q_stride * 2 < (1LL << 31) &&
+                  (long long)lq * do_stride * 2 < (1LL << 31), "ldm_attention_backward: a per-sample operand exceeds 2 GiB");
+  AttnBwdParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.q_stride = q_stride; p.kv_stride = kv_stride; p.o_stride = o_stride; p.do_stride = do_stride;
+  p.dq_stride = dq_stride; p.dkv_stride = dkv_stride;
+  p.batch = batch; p.heads = heads; p.lq = lq; p.lk = lk;
+  p.scale = 1.0f / sqrtf((float)d);
+  p.scale_log2e = p.scale * 1.4426950408889634f;
+  p.lse = lse; p.delta = delta_workspace;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d) {
+    case 40: return launch_attn_bwd<40>(p, st);
+    case 64: return launch_attn_bwd<64>(p, st);
+    case 80: return launch_attn_bwd<80>(p, st);
+    case 128: return launch_attn_bwd<128>(p, st);
+    case 160: return launch_attn_bwd<160>(p, st);
+    default: break;
+  }
+  set_error("ldm_attention_backward: head dim %d is not built (40, 64, 80, 128, 160)", d);
+  return LDM_EUNSUPPORTED;
+}

@@ -80,6 +80,11 @@ _SIGNATURES = {
     "ldm_layernorm": [c_void_p, c_int, c_i64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ldm_attention": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_void_p],
+    "ldm_attention_train": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_void_p, c_void_p],
+    "ldm_attention_backward": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                               c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_void_p],
     "ldm_timestep_embedding": [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p],
     "ldm_silu": [c_void_p, c_void_p, c_int, c_i64, c_void_p],
     "ldm_conv_in": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -441,6 +441,49 @@ def attention(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
     return out
 
 
+def attention_train(q: torch.Tensor, kv: torch.Tensor, heads: int):
+    """attention() that also returns lse (B, heads, Lq) float32 = log2 sum exp2 of the scaled scores, for the backward."""
+    _gpu(q, kv)
+    B, Lq, Cq = q.shape
+    Lk = kv.shape[1]
+    if kv.shape[2] != 2 * Cq or Cq % heads:
+        raise ValueError("attention: kv must have 2*C columns and C must divide into heads")
+    d = Cq // heads
+    out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, heads, Lq), dtype=torch.float32, device=q.device)
+    es = q.element_size()
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().ldm_attention_train(q.data_ptr(), q.stride(1), kv.data_ptr(), kv.data_ptr() + Cq * es,
+                                                   kv.stride(1), out.data_ptr(), out.stride(1), dt_code(q.dtype), B, heads,
+                                                   Lq, Lk, d, lse.data_ptr(), _stream(q)), "ldm_attention_train")
+    return out, lse
+
+
+def attention_backward(q, kv, out, dout, lse, heads, dq=None, dkv=None):
+    """Gradients of attention(q, kv): returns (dq (B, Lq, C), dkv (B, Lk, 2C): dK first, dV second).  dq / dkv may be
+    preallocated (row-strided) views, e.g. the column slices of one (B, L, 3C) buffer for the fused q|k|v projection."""
+    _gpu(q, kv, out, dout, lse, dq, dkv)
+    B, Lq, Cq = q.shape
+    Lk = kv.shape[1]
+    d = Cq // heads
+    if dq is None:
+        dq = torch.empty((B, Lq, Cq), dtype=q.dtype, device=q.device)
+    if dkv is None:
+        dkv = torch.empty((B, Lk, 2 * Cq), dtype=q.dtype, device=q.device)
+    for t in (q, kv, out, dout, dq, dkv):
+        if t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError("attention_backward: operands must be row-strided (B, L, C) views with unit column stride")
+    delta = torch.empty((B, heads, Lq), dtype=torch.float32, device=q.device)
+    es = q.element_size()
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().ldm_attention_backward(
+            q.data_ptr(), q.stride(1), kv.data_ptr(), kv.data_ptr() + Cq * es, kv.stride(1), out.data_ptr(), out.stride(1),
+            dout.data_ptr(), dout.stride(1), lse.data_ptr(), dq.data_ptr(), dq.stride(1), dkv.data_ptr(),
+            dkv.data_ptr() + Cq * es, dkv.stride(1), delta.data_ptr(), dt_code(q.dtype), B, heads, Lq, Lk, d, _stream(q)),
+            "ldm_attention_backward")
+    return dq, dkv
+
+
 def timestep_embedding(t: torch.Tensor, dim: int, dtype: torch.dtype) -> torch.Tensor:
     _gpu(t)
     t = t.to(torch.float32).contiguous()

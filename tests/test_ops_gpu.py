@@ -384,6 +384,40 @@ def test_layernorm_backward(dtype, rows, cols):
     assert rel_l2(dg2, 2 * g.grad) < 2e-5
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (2, 4, 128, 128, 80), (1, 8, 70, 77, 80),
+                                         (2, 2, 64, 64, 160), (1, 8, 100, 300, 160), (1, 2, 130, 190, 64)])
+def test_attention_backward(B, H, Lq, Lk, d):
+    """Flash backward (dq; dk, dv) against autograd of F.scaled_dot_product_attention in float32 on the same
+    bf16-rounded operands; also the lse the training forward saves."""
+    ops = _ops()
+    dt = torch.bfloat16
+    C = H * d
+    q, qr = _q(seeded((B, Lq, C), 1), dt)
+    kv, kvr = _q(seeded((B, Lk, 2 * C), 2), dt)
+    do, dor = _q(seeded((B, Lq, C), 3), dt)
+    out, lse = ops.attention_train(q, kv, H)
+    assert rel_l2(out, ops.attention(q, kv, H)) == 0.0
+    qg = qr.clone().requires_grad_(True)
+    kvg = kvr.clone().requires_grad_(True)
+
+    def heads(t):
+        return t.reshape(t.shape[0], t.shape[1], H, d).transpose(1, 2)
+    k_, v_ = kvg.chunk(2, dim=-1)
+    o_ref = F.scaled_dot_product_attention(heads(qg), heads(k_), heads(v_)).transpose(1, 2).reshape(B, Lq, C)
+    scores = (heads(qr) @ heads(kvr[..., :C]).transpose(-1, -2)) / math.sqrt(d)
+    assert rel_l2(lse, torch.logsumexp(scores, -1) * 1.4426950408889634) < 1e-3
+    o_ref.backward(dor)
+    dq, dkv = ops.attention_backward(q, kv, out, do, lse, H)
+    assert rel_l2(dq, qg.grad) < 2e-2
+    assert rel_l2(dkv[..., :C], kvg.grad[..., :C]) < 2e-2
+    assert rel_l2(dkv[..., C:], kvg.grad[..., C:]) < 2e-2
+    # strided outputs: the column slices of one fused (B, L, 3C) buffer (self-attention)
+    if Lq == Lk:
+        fused = torch.zeros(B, Lq, 3 * C, dtype=dt, device="cuda")
+        ops.attention_backward(q, kv, out, do, lse, H, dq=fused[..., :C], dkv=fused[..., C:])
+        assert torch.equal(fused[..., :C], dq) and torch.equal(fused[..., C:], dkv)
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32
