@@ -151,7 +151,8 @@ int ldm_conv_gemm_tile(const LdmConvGemm* desc, int tile[3]);
  * every nn.Conv2d / nn.Linear weight of ldm/unet.py.  `desc` describes the forward call (A operand, geometry, n, dtype;
  * w / epilogue / out are ignored); dy is [m][n] in desc->dtype.  accumulate != 0 adds to dw (gradient accumulation,
  * :1032).  `workspace`: DEVICE scratch of at least ldm_conv_wgrad_workspace_bytes(desc) bytes (fp32 partial tiles of
- * the pixel splits, folded in a fixed order: deterministic).  bf16 only this round. */
+ * the pixel splits, folded in a fixed order: deterministic).  bf16 with channel counts in multiples of 8 runs on the
+ * matrix cores; float32 (the exact parity path) and other channel counts run a plain-FMA kernel. */
 long long ldm_conv_wgrad_workspace_bytes(const LdmConvGemm* desc);
 int ldm_conv_wgrad(const LdmConvGemm* desc, const void* dy, float* dw, int accumulate, void* workspace,
                    long long workspace_bytes, void* stream);
@@ -197,17 +198,25 @@ int ldm_colsum(const void* x, int dtype, long long segments, long long rows_per_
 int ldm_glu_forward(const void* h, void* out, int dtype, long long rows, int ff, int gelu, void* stream);
 int ldm_glu_backward(const void* h, const void* dout, void* dh, int dtype, long long rows, int ff, int gelu, void* stream);
 
+/* out[r][c] = a[r*lda + c] + b[r*ldb + c], out dense [rows][cols]: where two gradient paths meet (skip connections,
+ * unet.py:313/:377, :731) and neither producer can fuse the add.  Row strides in elements, so an operand may be the
+ * channel slice of a concat gradient.  cols, lda, ldb multiples of 8. */
+int ldm_add(const void* a, long long lda, const void* b, long long ldb, void* out, int dtype, long long rows, int cols,
+            void* stream);
+
 /* dx = dy * d/dx silu(x)  (time-embedding MLP, unet.py:31, :703). */
 int ldm_silu_backward(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream);
 
 /* Backward of y = [SiLU](GroupNorm(x)) (unet.py:699-700, :705-706, :480, :113-114) on NHWC (two-source concat allowed):
  * dx (+ add, an optional second gradient arriving at x) for all c0+c1 channels, dgamma / dbeta (float32, (+)= when
- * accumulate).  stats: mean/rstd from ldm_groupnorm_stats.  dy, add, dx: [batch*hw][c0+c1] in dtype. */
+ * accumulate).  stats: mean/rstd from ldm_groupnorm_stats.  dy, add, dx: [batch*hw][c0+c1] in dtype.  dx1 != NULL (two
+ * sources only): the gradient of the concat (unet.py:313/:377) is split where it is produced -- dx [batch*hw][c0] for
+ * the hidden state, dx1 [batch*hw][c1] for the skip connection. */
 long long ldm_groupnorm_backward_workspace_floats(int batch, int channels, int groups);
 int ldm_groupnorm_backward(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups,
                            const float* stats, const float* gamma, const float* beta, int silu, const void* dy,
-                           const void* add, void* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
-                           void* stream);
+                           const void* add, void* dx, void* dx1, float* dgamma, float* dbeta, int accumulate,
+                           float* workspace, void* stream);
 
 /* Backward of nn.LayerNorm (unet.py:550-551, :576): statistics are recomputed from x. */
 long long ldm_layernorm_backward_workspace_floats(int cols);
@@ -231,7 +240,9 @@ int ldm_attention_train(const void* q, int q_stride, const void* k, const void* 
 /* Backward of F.scaled_dot_product_attention (unet.py:678): dq, dk, dv from q, k, v, the forward output o, its
  * gradient d_o and lse.  Flash-style (the score matrix is recomputed tile by tile, never stored), two deterministic
  * kernels (no atomics).  All tensors (rows, heads*d) with the given row strides, head h in columns [h*d, (h+1)*d);
- * dk and dv share dkv_stride.  delta_workspace: batch*heads*lq floats.  bf16, head dims 40/64/80/128/160. */
+ * dk and dv share dkv_stride.  delta_workspace: batch*heads*lq floats.  bf16 with head dims 40/64/80/128/160 and
+ * 16-byte-aligned operands runs on the matrix cores; float32 (the exact parity path) and other head dims <= 256 run
+ * a plain-FMA kernel of the same structure. */
 int ldm_attention_backward(const void* q, int q_stride, const void* k, const void* v, int kv_stride, const void* o,
                            int o_stride, const void* d_o, int do_stride, const float* lse, void* dq, int dq_stride,
                            void* dk, void* dv, int dkv_stride, float* delta_workspace, int dtype, int batch, int heads,

@@ -411,6 +411,171 @@ static int launch_attn_bwd(const AttnBwdParams& p, hipStream_t st) {
   return LDM_OK;
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Generic backward for any head dim <= 256 and either dtype (the exact-float32 parity path and the odd head dims of
+// small configurations; the forward's attention_generic_kernel is its counterpart).  Same two-kernel, atomic-free
+// structure, plain FMA arithmetic: a lane owns one row of the tile being swept for the score / dP dot products, then
+// the wave switches to one output column per lane for the accumulation.  Not a speed path.
+constexpr int GB_RPW = 4;       // rows (queries resp. keys) owned by a wave
+constexpr int GB_MAXD = 256;
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+attn_bwd_prep_generic_kernel(const AttnBwdParams p, int d) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // over batch*heads*lq
+  const int lane = threadIdx.x & 63;
+  if (row >= (long long)p.batch * p.heads * p.lq) return;
+  const int qi = (int)(row % p.lq);
+  const long long bh = row / p.lq;
+  const int h = (int)(bh % p.heads);
+  const long long b = bh / p.heads;
+  const T* o = static_cast<const T*>(p.o) + (b * p.lq + qi) * p.o_stride + h * d;
+  const T* g = static_cast<const T*>(p.d_o) + (b * p.lq + qi) * p.do_stride + h * d;
+  float s = 0.f;
+  for (int j = lane; j < d; j += 64) s += Elem<T>::ld(o + j) * Elem<T>::ld(g + j);
+  s = wave_sum(s);
+  if (lane == 0) p.delta[row] = s;
+}
+
+// SWEEP_KEYS: the workgroup owns 16 queries and sweeps the keys (dQ); else it owns 16 keys and sweeps the queries (dK, dV).
+template <typename T, bool SWEEP_KEYS>
+__global__ void __launch_bounds__(256)
+attn_bwd_generic_kernel(const AttnBwdParams p, int d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int dp = d + 1;
+  float* ta = reinterpret_cast<float*>(smem);             // [64][dp]  K tile      | Q tile
+  float* tb = ta + 64 * dp;                               // [64][dp]  V tile      | dO tile
+  float* ra = tb + 64 * dp;                               // [4][RPW][d]  own Q    | own K
+  float* rb = ra + 4 * GB_RPW * d;                        // [4][RPW][d]  own dO   | own V
+  float* ps = rb + 4 * GB_RPW * d;                        // [4][2][64]  per-wave P and dS of the current tile
+  float* tl = ps + 4 * 2 * 64;                            // [2][64]     lse / delta of the query tile (dK/dV pass)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int own = SWEEP_KEYS ? p.lq : p.lk, swept = SWEEP_KEYS ? p.lk : p.lq;
+  const int r0 = blockIdx.x * (4 * GB_RPW) + wave * GB_RPW;
+  const T* qp = static_cast<const T*>(p.q) + (size_t)b * p.lq * p.q_stride + h * d;
+  const T* kp = static_cast<const T*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * d;
+  const T* vp = static_cast<const T*>(p.v) + (size_t)b * p.lk * p.kv_stride + h * d;
+  const T* gp = static_cast<const T*>(p.d_o) + (size_t)b * p.lq * p.do_stride + h * d;
+  const float* lse = p.lse + ((size_t)b * p.heads + h) * p.lq;
+  const float* dl = p.delta + ((size_t)b * p.heads + h) * p.lq;
+
+  float* mya = ra + wave * GB_RPW * d;
+  float* myb = rb + wave * GB_RPW * d;
+  float* myp = ps + wave * 128;
+  for (int i = lane; i < GB_RPW * d; i += 64) {
+    const int rr = i / d, c = i - rr * d;
+    const bool ok = r0 + rr < own;
+    if (SWEEP_KEYS) {
+      mya[i] = ok ? Elem<T>::ld(qp + (size_t)(r0 + rr) * p.q_stride + c) : 0.f;
+      myb[i] = ok ? Elem<T>::ld(gp + (size_t)(r0 + rr) * p.do_stride + c) : 0.f;
+    } else {
+      mya[i] = ok ? Elem<T>::ld(kp + (size_t)(r0 + rr) * p.kv_stride + c) : 0.f;
+      myb[i] = ok ? Elem<T>::ld(vp + (size_t)(r0 + rr) * p.kv_stride + c) : 0.f;
+    }
+  }
+  constexpr int DPL = GB_MAXD / 64;
+  float acc0[GB_RPW][DPL], acc1[GB_RPW][DPL];             // dQ | (dK, dV)
+#pragma unroll
+  for (int rr = 0; rr < GB_RPW; ++rr)
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) { acc0[rr][k] = 0.f; acc1[rr][k] = 0.f; }
+
+  for (int t0 = 0; t0 < swept; t0 += 64) {
+    __syncthreads();
+    for (int i = tid; i < 64 * d; i += 256) {
+      const int row = i / d, c = i - row * d;
+      const bool ok = t0 + row < swept;
+      if (SWEEP_KEYS) {
+        ta[row * dp + c] = ok ? Elem<T>::ld(kp + (size_t)(t0 + row) * p.kv_stride + c) : 0.f;
+        tb[row * dp + c] = ok ? Elem<T>::ld(vp + (size_t)(t0 + row) * p.kv_stride + c) : 0.f;
+      } else {
+        ta[row * dp + c] = ok ? Elem<T>::ld(qp + (size_t)(t0 + row) * p.q_stride + c) : 0.f;
+        tb[row * dp + c] = ok ? Elem<T>::ld(gp + (size_t)(t0 + row) * p.do_stride + c) : 0.f;
+      }
+    }
+    if (!SWEEP_KEYS && tid < 64) {
+      const bool ok = t0 + tid < swept;
+      tl[tid] = ok ? lse[t0 + tid] : 0.f;
+      tl[64 + tid] = ok ? dl[t0 + tid] : 0.f;
+    }
+    __syncthreads();
+    const bool lane_ok = t0 + lane < swept;
+#pragma unroll
+    for (int rr = 0; rr < GB_RPW; ++rr) {
+      const bool row_ok = r0 + rr < own;                  // wave-uniform
+      float s = 0.f, dpv = 0.f;
+      for (int c = 0; c < d; ++c) {
+        s += mya[rr * d + c] * ta[lane * dp + c];         // q.k either way round
+        dpv += myb[rr * d + c] * tb[lane * dp + c];       // dO.v
+      }
+      float L, Dl;
+      if (SWEEP_KEYS) { L = row_ok ? lse[r0 + rr] : 0.f; Dl = row_ok ? dl[r0 + rr] : 0.f; }
+      else { L = tl[lane]; Dl = tl[64 + lane]; }
+      const float pr = (lane_ok && row_ok) ? exp2f(s * p.scale_log2e - L) : 0.f;
+      const float ds = pr * (dpv - Dl);
+      myp[lane] = pr;
+      myp[64 + lane] = ds;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        const int c = lane + 64 * k;
+        if (c < d) {
+          float a0 = acc0[rr][k], a1 = acc1[rr][k];
+          if (SWEEP_KEYS) {
+            for (int j = 0; j < 64; ++j) a0 += myp[64 + j] * ta[j * dp + c];            // dQ += dS K
+          } else {
+            for (int j = 0; j < 64; ++j) {
+              a0 += myp[64 + j] * ta[j * dp + c];                                      // dK += dS^T Q
+              a1 += myp[j] * tb[j * dp + c];                                           // dV += P^T dO
+            }
+          }
+          acc0[rr][k] = a0; acc1[rr][k] = a1;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < GB_RPW; ++rr) {
+    if (r0 + rr >= own) continue;
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) {
+      const int c = lane + 64 * k;
+      if (c >= d) continue;
+      if (SWEEP_KEYS) {
+        Elem<T>::st(static_cast<T*>(p.dq) + ((size_t)b * p.lq + r0 + rr) * p.dq_stride + h * d + c, acc0[rr][k] * p.scale);
+      } else {
+        Elem<T>::st(static_cast<T*>(p.dk) + ((size_t)b * p.lk + r0 + rr) * p.dkv_stride + h * d + c, acc0[rr][k] * p.scale);
+        Elem<T>::st(static_cast<T*>(p.dv) + ((size_t)b * p.lk + r0 + rr) * p.dkv_stride + h * d + c, acc1[rr][k]);
+      }
+    }
+  }
+}
+
+template <typename T>
+static int launch_attn_bwd_generic(const AttnBwdParams& p, int d, hipStream_t st) {
+  const size_t smem = ((size_t)2 * 64 * (d + 1) + 2 * 4 * GB_RPW * d + 4 * 2 * 64 + 2 * 64) * sizeof(float);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_generic_kernel<T, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_generic_kernel<T, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) { set_error("ldm_attention_backward: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+  }
+  const long long rows = (long long)p.batch * p.heads * p.lq;
+  hipLaunchKernelGGL((attn_bwd_prep_generic_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, d);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(generic prep)");
+  hipLaunchKernelGGL((attn_bwd_generic_kernel<T, true>), dim3((p.lq + 4 * GB_RPW - 1) / (4 * GB_RPW), p.heads, p.batch), dim3(256),
+                     smem, st, p, d);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(generic dq)");
+  hipLaunchKernelGGL((attn_bwd_generic_kernel<T, false>), dim3((p.lk + 4 * GB_RPW - 1) / (4 * GB_RPW), p.heads, p.batch), dim3(256),
+                     smem, st, p, d);
+  LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(generic dkv)");
+  return LDM_OK;
+}
+
 }  // namespace ldm
 
 using namespace ldm;
@@ -419,7 +584,7 @@ extern "C" int ldm_attention_backward(const void* q, int q_stride, const void* k
                                       int o_stride, const void* d_o, int do_stride, const float* lse, void* dq, int dq_stride,
                                       void* dk, void* dv, int dkv_stride, float* delta_workspace, int dtype, int batch,
                                       int heads, int lq, int lk, int d, void* stream) {
-  LDM_REQUIRE(dtype == LDM_BF16, "ldm_attention_backward: only the bf16 path is built (dtype %d)", dtype);
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_attention_backward: bad dtype %d", dtype);
   LDM_REQUIRE(batch >= 0 && heads >= 1 && lq >= 0 && lk >= 1 && d >= 1, "ldm_attention_backward: bad sizes");
   if (batch == 0 || lq == 0) return LDM_OK;
   LDM_REQUIRE(q && k && v && o && d_o && lse && dq && dk && dv && delta_workspace, "ldm_attention_backward: null pointer");
@@ -427,12 +592,11 @@ extern "C" int ldm_attention_backward(const void* q, int q_stride, const void* k
   LDM_REQUIRE(q_stride >= hd && kv_stride >= hd && o_stride >= hd && do_stride >= hd && dq_stride >= hd && dkv_stride >= hd,
               "ldm_attention_backward: row strides smaller than heads*d");
   LDM_REQUIRE(batch <= 65535 && heads <= 65535, "ldm_attention_backward: batch/heads exceed the grid limits");
-  LDM_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_o) && q_stride % 8 == 0 && kv_stride % 8 == 0 &&
-                  do_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 &&
-                  (reinterpret_cast<uintptr_t>(dv) & 7) == 0 && dq_stride % 4 == 0 && dkv_stride % 4 == 0,
-              "ldm_attention_backward: operands must be 16-byte aligned with strides in multiples of 8 elements");
-  LDM_REQUIRE((long long)lk * kv_stride * 2 < (1LL << 31) && (long long)lq * q_stride * 2 < (1LL << 31) &&
-                  (long long)lq * do_stride * 2 < (1LL << 31), "ldm_attention_backward: a per-sample operand exceeds 2 GiB");
+  const bool vec_ok = aligned16(q) && aligned16(k) && aligned16(v) && aligned16(d_o) && q_stride % 8 == 0 && kv_stride % 8 == 0 &&
+                      do_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(dq) & 7) == 0 && (reinterpret_cast<uintptr_t>(dk) & 7) == 0 &&
+                      (reinterpret_cast<uintptr_t>(dv) & 7) == 0 && dq_stride % 4 == 0 && dkv_stride % 4 == 0 &&
+                      (long long)lk * kv_stride * 2 < (1LL << 31) && (long long)lq * q_stride * 2 < (1LL << 31) &&
+                      (long long)lq * do_stride * 2 < (1LL << 31);
   AttnBwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
   p.q_stride = q_stride; p.kv_stride = kv_stride; p.o_stride = o_stride; p.do_stride = do_stride;
@@ -442,14 +606,16 @@ extern "C" int ldm_attention_backward(const void* q, int q_stride, const void* k
   p.scale_log2e = p.scale * 1.4426950408889634f;
   p.lse = lse; p.delta = delta_workspace;
   hipStream_t st = (hipStream_t)stream;
-  switch (d) {
-    case 40: return launch_attn_bwd<40>(p, st);
-    case 64: return launch_attn_bwd<64>(p, st);
-    case 80: return launch_attn_bwd<80>(p, st);
-    case 128: return launch_attn_bwd<128>(p, st);
-    case 160: return launch_attn_bwd<160>(p, st);
-    default: break;
+  if (dtype == LDM_BF16 && vec_ok) {
+    switch (d) {
+      case 40: return launch_attn_bwd<40>(p, st);
+      case 64: return launch_attn_bwd<64>(p, st);
+      case 80: return launch_attn_bwd<80>(p, st);
+      case 128: return launch_attn_bwd<128>(p, st);
+      case 160: return launch_attn_bwd<160>(p, st);
+      default: break;
+    }
   }
-  set_error("ldm_attention_backward: head dim %d is not built (40, 64, 80, 128, 160)", d);
-  return LDM_EUNSUPPORTED;
+  LDM_REQUIRE(d <= GB_MAXD, "ldm_attention_backward: head dim %d exceeds %d", d, GB_MAXD);
+  return dtype == LDM_BF16 ? launch_attn_bwd_generic<bf16_t>(p, d, st) : launch_attn_bwd_generic<float>(p, d, st);
 }

@@ -151,6 +151,24 @@ glu_bwd_kernel(const T* __restrict__ h, const T* __restrict__ dout, T* __restric
   store8(dh + off + 16, dg);
 }
 
+// out[r][c] = a[r][lda..] + b[r][ldb..] (gradient accumulation where two paths meet and neither producer can fuse the
+// add); the operands may be column slices of wider matrices (the two halves of a concat gradient)
+template <typename T>
+__global__ void __launch_bounds__(256)
+add_kernel(const T* __restrict__ a, long long lda, const T* __restrict__ b, long long ldb, T* __restrict__ out, int cpr,
+           long long nchunks) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nchunks) return;
+  const long long r = i / cpr;
+  const int c = (int)(i - r * cpr) * 8;
+  float x[8], y[8];
+  load8(a + r * lda + c, x);
+  load8(b + r * ldb + c, y);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] += y[e];
+  store8(out + i * 8, x);
+}
+
 // dx = dy * silu'(x)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -290,7 +308,7 @@ template <typename T>
 __global__ void __launch_bounds__(GB_THREADS)
 gn_bwd_apply_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T* __restrict__ dy, GnbGeom g,
                     const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-                    const float* __restrict__ gsum, const T* __restrict__ add, T* __restrict__ dx) {
+                    const float* __restrict__ gsum, const T* __restrict__ add, T* __restrict__ dx, T* __restrict__ dx1) {
   const int b = blockIdx.y, slab = blockIdx.x;
   const int tid = threadIdx.x;
   const int tp = tid / g.ct, tc = tid - tp * g.ct;
@@ -325,7 +343,10 @@ gn_bwd_apply_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const T*
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] += a[j];
     }
-    store8(dx + pixel * g.ctot + tc * 8, o);
+    // dx1 given: the two sources of the concat get their own dense gradients (c0 resp. c1 channels per pixel)
+    if (dx1 == nullptr) store8(dx + pixel * g.ctot + tc * 8, o);
+    else if (tc * 8 < g.c0) store8(dx + pixel * g.c0 + tc * 8, o);
+    else store8(dx1 + pixel * g.c1 + (tc * 8 - g.c0), o);
   }
 }
 
@@ -550,6 +571,24 @@ extern "C" int ldm_glu_backward(const void* h, const void* dout, void* dh, int d
   return LDM_OK;
 }
 
+extern "C" int ldm_add(const void* a, long long lda, const void* b, long long ldb, void* out, int dtype, long long rows, int cols,
+                       void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_add: bad dtype %d", dtype);
+  LDM_REQUIRE(rows >= 0 && cols >= 8 && cols % 8 == 0 && lda >= cols && ldb >= cols && lda % 8 == 0 && ldb % 8 == 0,
+              "ldm_add: cols and row strides must be multiples of 8 (rows=%lld cols=%d lda=%lld ldb=%lld)", rows, cols, lda, ldb);
+  if (rows == 0) return LDM_OK;
+  LDM_REQUIRE(a && b && out && aligned16(a) && aligned16(b) && aligned16(out), "ldm_add: null or unaligned pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const long long chunks = rows * (cols / 8);
+  const dim3 grid((unsigned)((chunks + 255) / 256));
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((add_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, cols / 8, chunks);
+  else
+    hipLaunchKernelGGL((add_kernel<float>), grid, dim3(256), 0, st, (const float*)a, lda, (const float*)b, ldb, (float*)out, cols / 8, chunks);
+  LDM_HIP_CHECK_LAUNCH("ldm_add");
+  return LDM_OK;
+}
+
 extern "C" int ldm_silu_backward(const void* x, const void* dy, void* dx, int dtype, long long n, void* stream) {
   LDM_REQUIRE(dtype_ok(dtype), "ldm_silu_backward: bad dtype %d", dtype);
   if (n <= 0) return LDM_OK;
@@ -568,9 +607,10 @@ extern "C" long long ldm_groupnorm_backward_workspace_floats(int batch, int chan
 
 extern "C" int ldm_groupnorm_backward(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups,
                                       const float* stats, const float* gamma, const float* beta, int silu, const void* dy,
-                                      const void* add, void* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
-                                      void* stream) {
+                                      const void* add, void* dx, void* dx1, float* dgamma, float* dbeta, int accumulate,
+                                      float* workspace, void* stream) {
   LDM_REQUIRE(dtype_ok(dtype), "ldm_groupnorm_backward: bad dtype %d", dtype);
+  LDM_REQUIRE(dx1 == nullptr || (c1 > 0 && aligned16(dx1)), "ldm_groupnorm_backward: dx1 needs a second source and 16-byte alignment");
   LDM_REQUIRE(batch >= 0 && hw >= 1, "ldm_groupnorm_backward: bad sizes");
   if (batch == 0) return LDM_OK;
   LDM_REQUIRE(batch <= 65535, "ldm_groupnorm_backward: batch %d exceeds 65535", batch);
@@ -603,10 +643,10 @@ extern "C" int ldm_groupnorm_backward(const void* a0, const void* a1, int c0, in
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_backward(param)");
   if (dtype == LDM_BF16)
     hipLaunchKernelGGL((gn_bwd_apply_kernel<bf16_t>), grid, dim3(GB_THREADS), 0, st, (const bf16_t*)a0, (const bf16_t*)a1,
-                       (const bf16_t*)dy, g, stats, gamma, beta, silu, gsum, (const bf16_t*)add, (bf16_t*)dx);
+                       (const bf16_t*)dy, g, stats, gamma, beta, silu, gsum, (const bf16_t*)add, (bf16_t*)dx, (bf16_t*)dx1);
   else
     hipLaunchKernelGGL((gn_bwd_apply_kernel<float>), grid, dim3(GB_THREADS), 0, st, (const float*)a0, (const float*)a1,
-                       (const float*)dy, g, stats, gamma, beta, silu, gsum, (const float*)add, (float*)dx);
+                       (const float*)dy, g, stats, gamma, beta, silu, gsum, (const float*)add, (float*)dx, (float*)dx1);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_backward(apply)");
   return LDM_OK;
 }

@@ -209,6 +209,47 @@ wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int
   dw[idx] = v;
 }
 
+
+// Plain-FMA weight gradient for either dtype and any channel count: the exact-float32 parity path.  One thread per
+// dW element and pixel split; the same partial buffer and fold kernel as above.  Not a speed path.
+constexpr int WGG_ROWS = 1024;   // pixels per split
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_wgrad_generic_kernel(const WgradParams p) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over [N][K]
+  if (idx >= (long long)p.N * p.K) return;
+  const int n = (int)(idx / p.K), k = (int)(idx - (long long)n * p.K);
+  const int tap = k / p.ctot;
+  int c = k - tap * p.ctot;
+  const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+  const bool second = c >= p.c0;
+  if (second) c -= p.c0;
+  const T* src = static_cast<const T*>(second ? p.a1 : p.a0);
+  const int cs = second ? p.c1 : p.c0;
+  const T* dy = static_cast<const T*>(p.dy);
+  const int hlim = p.upsample ? p.hin * 2 : p.hin, wlim = p.upsample ? p.win * 2 : p.win;
+  const int pad = p.ksize >> 1;
+  const int m0 = blockIdx.y * WGG_ROWS, m1 = min(m0 + WGG_ROWS, p.M);
+  const int hw_out = p.hout * p.wout;
+  int b = m0 / hw_out, rem = m0 - b * hw_out;
+  int oh = rem / p.wout, ow = rem - oh * p.wout;
+  float acc = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    int ih = oh * p.stride - pad + kh, iw = ow * p.stride - pad + kw;
+    if (ih >= 0 && ih < hlim && iw >= 0 && iw < wlim) {
+      if (p.upsample) { ih >>= 1; iw >>= 1; }
+      acc += Elem<T>::ld(dy + (size_t)m * p.N + n) * Elem<T>::ld(src + ((size_t)(b * p.hin + ih) * p.win + iw) * cs + c);
+    }
+    if (++ow == p.wout) { ow = 0; if (++oh == p.hout) { oh = 0; ++b; } }
+  }
+  p.partial[(size_t)blockIdx.y * p.N * p.K + idx] = acc;
+}
+
+static bool wgrad_use_mfma(const LdmConvGemm* d) {
+  return d->dtype == LDM_BF16 && (d->c0 + d->c1) % 8 == 0 && d->c0 % 8 == 0 && d->n % 8 == 0;
+}
+
 static void wgrad_plan(const LdmConvGemm* d, WgradParams& p) {
   p.c0 = d->c0; p.c1 = d->c1; p.ctot = d->c0 + d->c1;
   p.batch = d->batch; p.hin = d->hin; p.win = d->win; p.hout = d->hout; p.wout = d->wout;
@@ -216,6 +257,12 @@ static void wgrad_plan(const LdmConvGemm* d, WgradParams& p) {
   p.M = d->batch * d->hout * d->wout; p.N = d->n; p.K = d->ksize * d->ksize * p.ctot;
   p.tiles_n = (p.N + WG_TN - 1) / WG_TN;
   p.tiles_k = (p.K + WG_TK - 1) / WG_TK;
+  if (!wgrad_use_mfma(d)) {
+    p.splits = (p.M + WGG_ROWS - 1) / WGG_ROWS;
+    if (p.splits < 1) p.splits = 1;
+    p.steps_per_split = 0;
+    return;
+  }
   const int steps = (p.M + WG_MS - 1) / WG_MS;
   // enough workgroups for two per CU, at least 8 steps each
   int splits = (512 + p.tiles_n * p.tiles_k - 1) / (p.tiles_n * p.tiles_k);
@@ -240,7 +287,7 @@ extern "C" long long ldm_conv_wgrad_workspace_bytes(const LdmConvGemm* d) {
 extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, int accumulate, void* workspace,
                               long long workspace_bytes, void* stream) {
   LDM_REQUIRE(d != nullptr, "ldm_conv_wgrad: null descriptor");
-  LDM_REQUIRE(d->dtype == LDM_BF16, "ldm_conv_wgrad: only the bf16 path is built (dtype %d)", d->dtype);
+  LDM_REQUIRE(dtype_ok(d->dtype), "ldm_conv_wgrad: bad dtype %d", d->dtype);
   LDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "ldm_conv_wgrad: ksize must be 1 or 3 (got %d)", d->ksize);
   LDM_REQUIRE(d->stride == 1 || d->stride == 2, "ldm_conv_wgrad: stride must be 1 or 2 (got %d)", d->stride);
   LDM_REQUIRE(!(d->upsample && d->stride != 1), "ldm_conv_wgrad: upsample with stride 2 is not a thing");
@@ -263,25 +310,33 @@ extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, i
     return LDM_OK;
   }
   LDM_REQUIRE(d->a0 && dy && (d->c1 == 0 || d->a1), "ldm_conv_wgrad: null pointer");
-  LDM_REQUIRE(p.ctot % 8 == 0 && p.c0 % 8 == 0, "ldm_conv_wgrad: channel counts must be multiples of 8 (c0=%d c1=%d)", d->c0, d->c1);
-  LDM_REQUIRE(d->n % 8 == 0, "ldm_conv_wgrad: n must be a multiple of 8 (got %d)", d->n);
+  const bool mfma = wgrad_use_mfma(d);
   const long long pix = (long long)d->batch * d->hin * d->win;
-  LDM_REQUIRE(pix * d->c0 * 2 < (1LL << 31) && pix * d->c1 * 2 < (1LL << 31) && (long long)p.M * p.N * 2 < (1LL << 31),
-              "ldm_conv_wgrad: an operand exceeds 2 GiB (32-bit buffer offsets)");
-  LDM_REQUIRE(aligned16(d->a0) && (d->c1 == 0 || aligned16(d->a1)) && aligned16(dy), "ldm_conv_wgrad: operands must be 16-byte aligned");
+  if (mfma) {
+    LDM_REQUIRE(pix * d->c0 * 2 < (1LL << 31) && pix * d->c1 * 2 < (1LL << 31) && (long long)p.M * p.N * 2 < (1LL << 31),
+                "ldm_conv_wgrad: an operand exceeds 2 GiB (32-bit buffer offsets)");
+    LDM_REQUIRE(aligned16(d->a0) && (d->c1 == 0 || aligned16(d->a1)) && aligned16(dy), "ldm_conv_wgrad: operands must be 16-byte aligned");
+  }
+  LDM_REQUIRE(pix < (1LL << 31) && (long long)p.M < (1LL << 31) && p.splits <= 65535, "ldm_conv_wgrad: too many pixels");
   const long long need = (long long)p.splits * p.N * p.K * 4;
   LDM_REQUIRE(workspace != nullptr && workspace_bytes >= need, "ldm_conv_wgrad: workspace of %lld bytes needed (got %lld)", need,
               workspace_bytes);
   p.a0 = d->a0; p.a1 = d->c1 ? d->a1 : d->a0; p.dy = dy; p.partial = static_cast<float*>(workspace);
-  const int smem = 2 * WG_STAGE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
-    attr_done = true;
+  if (mfma) {
+    const int smem = 2 * WG_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+      attr_done = true;
+    }
+    dim3 grid(p.tiles_n * p.tiles_k, p.splits);
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), smem, st, p);
+  } else {
+    dim3 grid((unsigned)(((long long)p.N * p.K + 255) / 256), p.splits);
+    if (d->dtype == LDM_BF16) hipLaunchKernelGGL((conv_wgrad_generic_kernel<bf16_t>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_generic_kernel<float>), grid, dim3(256), 0, st, p);
   }
-  dim3 grid(p.tiles_n * p.tiles_k, p.splits);
-  hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_wgrad");
   const long long total = (long long)p.N * p.K;
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot,

@@ -67,9 +67,10 @@ _SIGNATURES = {
     "ldm_colsum": [c_void_p, c_int, C.c_longlong, C.c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "ldm_glu_forward": [c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
     "ldm_glu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
+    "ldm_add": [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_int, C.c_longlong, c_int, c_void_p],
     "ldm_silu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_void_p],
     "ldm_groupnorm_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ldm_layernorm_backward": [c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "ldm_groupnorm_workspace_floats": [c_int, c_int],

@@ -177,8 +177,8 @@ def conv_wgrad(a0: torch.Tensor, dy: torch.Tensor, *, a1: Optional[torch.Tensor]
     """Weight gradient of conv_gemm(a0, w, a1=..., ksize=..., stride=..., upsample=...): float32, checkpoint layout
     ([N, C0+C1, k, k], or [N, C] for ksize == 1 matrices).  ``out``: an existing gradient to accumulate into."""
     _gpu(a0, a1, dy, out)
-    if a0.dtype != torch.bfloat16 or dy.dtype != torch.bfloat16:
-        raise TypeError("conv_wgrad: bf16 activations and output gradients (the float32 path is not built yet)")
+    if a0.dtype != dy.dtype or (a1 is not None and a1.dtype != a0.dtype):
+        raise TypeError("conv_wgrad: activations and output gradients must share one dtype")
     if not a0.is_contiguous() or not dy.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
         raise ValueError("conv_wgrad: activations and dy must be contiguous")
     c0 = a0.shape[-1]
@@ -320,9 +320,11 @@ def _bwd_workspace(device, nfloats: int) -> torch.Tensor:
     return ws
 
 
-def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=False, add=None, dgamma=None, dbeta=None):
+def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=False, add=None, dgamma=None, dbeta=None,
+                       split=False):
     """Backward of groupnorm(a0, ..., a1=a1, silu=silu): returns (dx over all c0+c1 channels [+ add], dgamma, dbeta).
-    dgamma / dbeta given: accumulated into (float32)."""
+    dgamma / dbeta given: accumulated into (float32).  split (two sources): dx is the pair (dx0 (.., c0), dx1 (.., c1)),
+    each dense -- the concat gradient is split where it is produced."""
     _gpu(a0, a1, stats, gamma, beta, dy, add, dgamma, dbeta)
     B = a0.shape[0]
     c0 = a0.shape[-1]
@@ -330,19 +332,25 @@ def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=Fals
     hw = a0.numel() // (B * c0) if B else 1
     if not dy.is_contiguous() or dy.shape[-1] != c0 + c1 or dy.dtype != a0.dtype:
         raise ValueError("groupnorm_backward: dy must be contiguous (.., c0+c1) in the activation dtype")
+    if add is not None and (not add.is_contiguous() or add.shape != dy.shape):
+        raise ValueError("groupnorm_backward: add must be contiguous with dy's shape")
     accumulate = dgamma is not None
     if not accumulate:
         dgamma = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
         dbeta = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
-    dx = torch.empty_like(dy)
+    if split and a1 is not None:
+        dx = torch.empty_like(a0)
+        dx1 = torch.empty_like(a1)
+    else:
+        dx, dx1 = torch.empty_like(dy), None
     lib = _lib.load()
     with torch.cuda.device(a0.device):
         ws = _bwd_workspace(a0.device, lib.ldm_groupnorm_backward_workspace_floats(B, c0 + c1, groups))
         _lib.check(lib.ldm_groupnorm_backward(a0.data_ptr(), _ptr(a1), c0, c1, dt_code(a0.dtype), B, hw, groups, stats.data_ptr(),
                                               gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, dy.data_ptr(), _ptr(add),
-                                              dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 1 if accumulate else 0,
-                                              ws.data_ptr(), _stream(a0)), "ldm_groupnorm_backward")
-    return dx, dgamma, dbeta
+                                              dx.data_ptr(), _ptr(dx1), dgamma.data_ptr(), dbeta.data_ptr(),
+                                              1 if accumulate else 0, ws.data_ptr(), _stream(a0)), "ldm_groupnorm_backward")
+    return ((dx, dx1) if dx1 is not None else dx), dgamma, dbeta
 
 
 def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None, dbeta=None):
@@ -402,6 +410,35 @@ def glu_backward(h: torch.Tensor, dout: torch.Tensor, act: str) -> torch.Tensor:
                                                 h.numel() // (2 * ff), ff, 1 if act == "geglu" else 0, _stream(h)),
                    "ldm_glu_backward")
     return dh
+
+
+def _rows_view(t: torch.Tensor):
+    """(rows, cols, row stride) of a tensor that is a dense matrix or a column slice of one."""
+    cols = t.shape[-1]
+    rows = t.numel() // cols if cols else 0
+    if t.stride(-1) != 1:
+        raise ValueError("operand must have unit column stride")
+    ld = t.stride(-2) if t.dim() > 1 else cols
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):      # leading dimensions must be a plain row enumeration
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError("operand must be a row-strided matrix view")
+        exp *= t.shape[d]
+    return rows, cols, ld
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a + b -> dense tensor; a and b may be column slices of wider matrices (halves of a concat gradient)."""
+    _gpu(a, b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError("add: operands must have equal shape and dtype")
+    rows, cols, lda = _rows_view(a)
+    _, _, ldb = _rows_view(b)
+    out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().ldm_add(a.data_ptr(), lda, b.data_ptr(), ldb, out.data_ptr(), dt_code(a.dtype), rows, cols,
+                                       _stream(a)), "ldm_add")
+    return out
 
 
 def silu_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:

@@ -16,7 +16,9 @@ arithmetic is a straight-line schedule of C-ABI kernel launches (``ops.py`` -> `
 The reference's quirks are reproduced: no skip around TransformerModel, no residual around
 the feed-forward, attn2 always 8 heads, K = first half of kv_proj, GEGLU value = first half, GN/LN eps 1e-5.
 
-There is no CPU fallback and (this round) no backward: calling with autograd recording enabled raises.
+There is no CPU fallback.  With autograd recording (the trainer's loss.backward(), train_latent_diffusion.py:1119) the
+call runs the training form of the same schedule (``_train.py``): one autograd node per module call whose backward is
+the hand-scheduled chain of HIP backward kernels; parameter gradients arrive as ordinary ``.grad`` tensors.
 """
 from __future__ import annotations
 
@@ -25,7 +27,7 @@ from typing import List, Optional, Union
 import torch
 from torch import nn
 
-from . import ops
+from . import _train, ops
 
 
 def _j(prefix: str, name: str) -> str:
@@ -48,10 +50,15 @@ def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
 
 
 # --------------------------------------------------------------------------------------- packed weights
-def pack_tree(root: nn.Module, dtype: torch.dtype) -> dict:
+def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
     """Derived, K-contiguous copies of every filter under ``root`` in the compute dtype, keyed by module path.
-    Checkpoint layout stays PyTorch's ([out, in, kh, kw]); these are rebuilt when a parameter changes."""
+    Checkpoint layout stays PyTorch's ([out, in, kh, kw]); these are rebuilt when a parameter changes.
+    train: also the filters of the input-gradient pass (``.wd``: in/out transposed, taps rotated)."""
     P = {}
+
+    def dgrad(key, w):
+        if train:
+            P[key + ".wd"] = ops.pack_weight_dgrad(w, dtype)
 
     def f32(p):
         return p.detach().to(torch.float32).contiguous()
@@ -66,6 +73,7 @@ def pack_tree(root: nn.Module, dtype: torch.dtype) -> dict:
             elif isinstance(mod, (nn.Conv2d, nn.Linear)):
                 glu = name.endswith("w1_w2")
                 P[name + ".w"] = ops.pack_weight(mod.weight, dtype, glu_pairs=glu)
+                dgrad(name, _train.glu_rows_to_packed(mod.weight.detach()) if glu else mod.weight)
                 if mod.bias is not None:
                     P[name + ".b"] = ops.pack_weight(mod.bias, torch.float32, glu_pairs=True).flatten() if glu \
                         else f32(mod.bias)
@@ -73,11 +81,15 @@ def pack_tree(root: nn.Module, dtype: torch.dtype) -> dict:
                 P[name + ".g"] = f32(mod.weight)
                 P[name + ".b"] = f32(mod.bias)
             if isinstance(mod, Attention) and mod.fused_qkv:
-                P[_j(name, "qkv.w")] = ops.pack_weight(torch.cat([mod.q_proj.weight, mod.kv_proj.weight], 0), dtype)
+                wqkv = torch.cat([mod.q_proj.weight, mod.kv_proj.weight], 0)
+                P[_j(name, "qkv.w")] = ops.pack_weight(wqkv, dtype)
+                dgrad(_j(name, "qkv"), wqkv)
         resnets = [(n, m) for n, m in root.named_modules() if isinstance(m, ResnetBlock)]
         if isinstance(root, UNet) and resnets:
             # all time projections (unet.py:703) as one filter; each resnet reads its column slice
-            P["time_all.w"] = ops.pack_weight(torch.cat([m.time[1].weight for _, m in resnets], 0), dtype)
+            wt = torch.cat([m.time[1].weight for _, m in resnets], 0)
+            P["time_all.w"] = ops.pack_weight(wt, dtype)
+            dgrad("time_all", wt)
             P["time_all.b"] = f32(torch.cat([m.time[1].bias for _, m in resnets], 0))
             off = 0
             for n, m in resnets:
@@ -89,25 +101,28 @@ def pack_tree(root: nn.Module, dtype: torch.dtype) -> dict:
 class _HipModule(nn.Module):
     """Caches the packed weights of the tree rooted here until any parameter changes (optimizer step, load)."""
 
-    def _packed_for(self, dtype: torch.dtype) -> dict:
+    def _packed_for(self, dtype: torch.dtype, train: bool = False) -> dict:
         ver = tuple((p._version, p.data_ptr()) for p in self.parameters())
         cache = self.__dict__.setdefault("_ldm_cache", {})
         if cache.get("ver") != ver:
             cache.clear()
             cache["ver"] = ver
-        if dtype not in cache:
-            cache[dtype] = pack_tree(self, dtype)
-        return cache[dtype]
+        key = (dtype, train)
+        if key not in cache:
+            if train and (dtype, False) in cache:
+                cache.pop((dtype, False))      # the training set contains the inference set
+            cache[key] = pack_tree(self, dtype, train)
+        return cache[key]
 
-    def _check_call(self, x: torch.Tensor):
+    def _check_call(self, x: torch.Tensor, *others) -> bool:
+        """Validates the call; True when autograd is recording and the training form must run."""
         if not x.is_cuda:
             raise RuntimeError("ldm_amd: tensors must live on an AMD GPU (there is no CPU fallback)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("ldm_amd: the HIP backward is not built yet; call under torch.no_grad() / "
-                                      "torch.inference_mode()")
         p = next(self.parameters(), None)
         if p is not None and p.device != x.device:
             raise RuntimeError("ldm_amd: parameters and input are on different devices")
+        return torch.is_grad_enabled() and (x.requires_grad or any(torch.is_tensor(o) and o.requires_grad for o in others)
+                                            or any(q.requires_grad for q in self.parameters()))
 
 
 def _to_nhwc(x: torch.Tensor, dt: torch.dtype) -> torch.Tensor:
@@ -187,11 +202,24 @@ class ResnetBlock(_HipModule):
         self.in_channels, self.out_channels, self.norm_num_groups = in_channels, out_channels, int(norm_num_groups)
 
     def forward(self, input_tensor: torch.Tensor, temb: torch.Tensor) -> torch.Tensor:
-        self._check_call(input_tensor)
         dt = compute_dtype_of(input_tensor)
+        if self._check_call(input_tensor, temb):
+            return _train.apply(self, lambda ins, needs: self._train_form(dt, needs, *ins), (input_tensor, temb))
         P = self._packed_for(dt)
         rowvec = ops.conv_gemm(ops.silu(temb.to(dt)), P["time.1.w"], bias=P["time.1.b"])
         return _to_nchw(run_resnet(P, "", self, _to_nhwc(input_tensor, dt), None, rowvec))
+
+    def _train_form(self, dt, needs, input_tensor, temb):
+        T = _train.Tape(self._packed_for(dt, train=True), dt)
+        te = temb.to(dt).contiguous()
+        rowvec, rv_bwd = _train.conv_train(T, "time.1", ops.silu(te))
+        out, b = _train.resnet_train(T, "", self, _to_nhwc(input_tensor, dt), None, rowvec)
+
+        def bwd(dout):
+            dx, _, drow = b(_to_nhwc(dout, dt))
+            dtemb = ops.silu_backward(te, rv_bwd(drow.to(dt)))
+            return _to_nchw(dx), dtemb
+        return _to_nchw(out), bwd, T
 
 
 class Attention(_HipModule):
@@ -215,11 +243,18 @@ class Attention(_HipModule):
         return self
 
     def forward(self, in_features: torch.Tensor, cross_features: Optional[torch.Tensor] = None) -> torch.Tensor:
-        self._check_call(in_features)
         dt = compute_dtype_of(in_features)
+        if self._check_call(in_features, cross_features):
+            return _train.apply(self, lambda ins, needs: self._train_form(dt, needs, *ins), (in_features, cross_features))
         P = self._packed_for(dt)
         ctx = None if cross_features is None else cross_features.to(dt).contiguous()
         return run_attention(P, "", self, in_features.to(dt).contiguous(), ctx)
+
+    def _train_form(self, dt, needs, in_features, cross_features):
+        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1])
+        ctx = None if cross_features is None else cross_features.to(dt).contiguous()
+        out, b = _train.attention_train(T, "", self, in_features.to(dt).contiguous(), ctx)
+        return out, (lambda dout: (b(dout.to(dt)), T.dctx)), T
 
 
 class _GatedProjection(nn.Module):
@@ -263,11 +298,18 @@ class TransformerBlock(_HipModule):
         self.feed_forward = _seq(nn.LayerNorm(in_channels), act, nn.Identity(), nn.Linear(ff_dim, in_channels))
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: torch.Tensor) -> torch.Tensor:
-        self._check_call(hidden_states)
         dt = compute_dtype_of(hidden_states)
+        if self._check_call(hidden_states, encoder_hidden_states):
+            return _train.apply(self, lambda ins, needs: self._train_form(dt, needs, *ins), (hidden_states, encoder_hidden_states))
         P = self._packed_for(dt)
         return run_transformer_block(P, "", self, hidden_states.to(dt).contiguous(),
                                      encoder_hidden_states.to(dt).contiguous())
+
+    def _train_form(self, dt, needs, hidden_states, encoder_hidden_states):
+        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1])
+        out, b = _train.transformer_block_train(T, "", self, hidden_states.to(dt).contiguous(),
+                                                encoder_hidden_states.to(dt).contiguous())
+        return out, (lambda dout: (b(dout.to(dt)), T.dctx)), T
 
 
 class TransformerModel(_HipModule):
@@ -287,11 +329,18 @@ class TransformerModel(_HipModule):
         self.proj_out = nn.Conv2d(in_channels, in_channels, 1)
 
     def forward(self, hidden_states: torch.Tensor, encoder_hidden_states: Optional[torch.Tensor] = None) -> torch.Tensor:
-        self._check_call(hidden_states)
         dt = compute_dtype_of(hidden_states)
+        if self._check_call(hidden_states, encoder_hidden_states):
+            return _train.apply(self, lambda ins, needs: self._train_form(dt, needs, *ins), (hidden_states, encoder_hidden_states))
         P = self._packed_for(dt)
         return _to_nchw(run_transformer_model(P, "", self, _to_nhwc(hidden_states, dt),
                                               encoder_hidden_states.to(dt).contiguous()))
+
+    def _train_form(self, dt, needs, hidden_states, encoder_hidden_states):
+        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1])
+        out, b = _train.transformer_model_train(T, "", self, _to_nhwc(hidden_states, dt),
+                                                encoder_hidden_states.to(dt).contiguous())
+        return _to_nchw(out), (lambda dout: (_to_nchw(b(_to_nhwc(dout, dt))), T.dctx)), T
 
 
 class _Stage(nn.Module):
@@ -359,9 +408,8 @@ class UNet(_HipModule):
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
                 encoder_hidden_states: torch.Tensor) -> torch.Tensor:
-        self._check_call(sample)
+        train = self._check_call(sample, encoder_hidden_states)
         dt = compute_dtype_of(sample)
-        P = self._packed_for(dt)
         B = sample.shape[0]
         dev = sample.device
 
@@ -372,6 +420,9 @@ class UNet(_HipModule):
         elif t.dim() == 0:
             t = t[None]
         t = t.to(dev, non_blocking=True).expand(B).to(torch.float32)
+        if train:
+            return _train.apply(self, lambda ins, needs: self._train_form(dt, t, needs, *ins), (sample, encoder_hidden_states))
+        P = self._packed_for(dt)
 
         emb = ops.timestep_embedding(t, self.block_out_channels[0], dt)
         e = ops.conv_gemm(emb, P["time_embedding.0.w"], bias=P["time_embedding.0.b"], silu=True)
@@ -411,3 +462,8 @@ class UNet(_HipModule):
                 h = ops.conv_gemm(h, P[nm + ".w"], ksize=3, upsample=True, bias=P[nm + ".b"])
         h = ops.groupnorm(h, P["final_conv.0.g"], P["final_conv.0.b"], self.norm_num_groups, silu=True)
         return ops.conv_out(h, P["final_conv.2.w"], P["final_conv.2.b"], dt)
+
+    def _train_form(self, dt, t, needs, sample, encoder_hidden_states):
+        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1])
+        out, b = _train.unet_train(T, self, sample, t, encoder_hidden_states.to(dt).contiguous(), needs[0])
+        return out, (lambda dout: (b(dout), T.dctx)), T
