@@ -30,15 +30,20 @@ def _j(prefix: str, name: str) -> str:
 class Tape:
     """Packed weights + the parameter gradients collected by one backward pass."""
 
-    def __init__(self, P: dict, dtype: torch.dtype, need_ctx_grad: bool = False):
+    def __init__(self, P: dict, dtype: torch.dtype, need_ctx_grad: bool = False, sink=None):
         self.P = P
         self.dt = dtype
         self.grads: Dict[str, torch.Tensor] = {}
         self.need_ctx_grad = need_ctx_grad
         self.dctx: Optional[torch.Tensor] = None
+        self.sink = sink            # ldm.parallel.GradReducer: finished parameter gradients go to its buckets at once
 
     # ------------------------------------------------------------------ parameter gradients
     def put(self, key: str, g: torch.Tensor):
+        """A finished gradient.  Keys that are not parameter names (fused filters: qkv, time_all) are intermediate:
+        their owners split them and put the parts under the parameters' names."""
+        if self.sink is not None and key in self.sink.params and self.sink.params[key].requires_grad:
+            g = self.sink.put(key, g)           # -> view of a flat bucket, averaged once the pass finishes
         self.grads[key] = g if key not in self.grads else self.grads[key] + g
 
     def weight_grad(self, name: str, a0, dy, *, a1=None, ksize=1, stride=1, upsample=False):
@@ -64,7 +69,7 @@ def glu_rows_to_packed(w: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------ layers
 def conv_train(T: Tape, name: str, a0, *, a1=None, ksize=1, stride=1, upsample=False, rowvec=None, residual=None,
-               has_bias=True):
+               has_bias=True, grad_map=None):
     """ops.conv_gemm + backward closure.  bwd(dy, need_dx=True, add=None) -> dx over all c0+c1 channels (+ add).
     The gradient of ``residual`` is dy itself; the gradient of ``rowvec`` is colsum(dy, segments=B) (callers do both)."""
     P = T.P
@@ -73,9 +78,11 @@ def conv_train(T: Tape, name: str, a0, *, a1=None, ksize=1, stride=1, upsample=F
     in_hw = (a0.shape[1], a0.shape[2]) if a0.dim() == 4 else None
 
     def bwd(dy, need_dx=True, add=None, bias_from=None):
-        T.put(name + ".weight", T.weight_grad(name, a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample))
+        gw = T.weight_grad(name, a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample)
+        T.put(name + ".weight", gw if grad_map is None else grad_map(gw))
         if has_bias:
-            T.put(name + ".bias", T.bias_grad(dy) if bias_from is None else bias_from)
+            gb = T.bias_grad(dy) if bias_from is None else bias_from
+            T.put(name + ".bias", gb if grad_map is None else grad_map(gb))
         if not need_dx:
             return None
         dx = ops.conv_dgrad(dy, P[name + ".wd"], ksize=ksize, stride=stride, upsample=upsample, in_hw=in_hw, residual=add)
@@ -171,7 +178,8 @@ def transformer_block_train(T: Tape, n: str, blk, x, ctx):
     y2 = ln("norm2", x1)
     x2, a2_bwd = attention_train(T, _j(n, "attn2"), blk.attn2, y2, ctx, residual=x1)
     y3 = ln("feed_forward.0", x2)
-    hpre, h_bwd = conv_train(T, _j(n, "feed_forward.1.w1_w2"), y3)          # packed (value|gate interleaved) columns
+    hpre, h_bwd = conv_train(T, _j(n, "feed_forward.1.w1_w2"), y3,          # packed (value|gate interleaved) columns
+                             grad_map=glu_rows_to_checkpoint)
     gl = ops.glu_forward(hpre, blk.activation_fn)
     out, o_bwd = conv_train(T, _j(n, "feed_forward.3"), gl)                 # no residual round the FF (:595)
 
@@ -179,9 +187,6 @@ def transformer_block_train(T: Tape, n: str, blk, x, ctx):
         dgl = o_bwd(dout)
         dh = ops.glu_backward(hpre, dgl, blk.activation_fn)
         dy3 = h_bwd(dh)
-        kw, kb = _j(n, "feed_forward.1.w1_w2.weight"), _j(n, "feed_forward.1.w1_w2.bias")
-        T.grads[kw] = glu_rows_to_checkpoint(T.grads[kw])
-        T.grads[kb] = glu_rows_to_checkpoint(T.grads[kb])
         dx2 = ln_bwd("feed_forward.0", x2, dy3)
         dy2 = a2_bwd(dx2)
         dx1 = ln_bwd("norm2", x1, dy2, add=dx2)
@@ -407,8 +412,13 @@ class TrainFunction(torch.autograd.Function):
     def backward(ctx, dout):
         if ctx.bwd is None:
             raise RuntimeError("ldm_amd: backward through this UNet call ran twice (activations are freed after the first)")
+        sink = ctx.tape.sink
+        if sink is not None:
+            sink.begin()
         din = ctx.bwd(_dense(dout))
         grads = ctx.tape.grads
+        if sink is not None:
+            grads.update(sink.finish())          # all-reduces launched during the pass are complete (stream-ordered)
         res = [None, None, None]
         for i, meta in enumerate(ctx.in_meta):
             g = din[i] if din is not None and i < len(din) else None
@@ -421,7 +431,8 @@ class TrainFunction(torch.autograd.Function):
             if g is None or not ctx.needs_input_grad[3 + ctx.n_in + j]:
                 res.append(None)
             else:
-                res.append(g.reshape(shape).to(dtype))
+                g = g.reshape(shape).to(dtype)
+                res.append(g.clone() if sink is not None and g.dtype == torch.float32 else g)   # never alias a bucket
         ctx.bwd = ctx.tape = None      # drop the saved activations
         return tuple(res)
 

@@ -1,0 +1,170 @@
+"""Data-parallel training of the UNet over RCCL / xGMI: bucketed gradient all-reduce overlapped with the backward.
+
+The reference never names a collective: ``accelerator.prepare(model)`` (train_latent_diffusion.py:947) wraps the UNet in
+torch DDP when launched with more than one process, and DDP's reducer all-reduces 25 MB gradient buckets as autograd
+produces them (``accelerator.backward`` :1119, ``accumulate`` / ``no_sync`` :1032).  The HIP UNet is ONE autograd node
+(ldm/_train.py), so torch DDP would see every gradient at the same instant, after the whole backward.  The overlap
+therefore lives inside the hand-scheduled backward: ``Tape.put`` hands each finished parameter gradient to a
+``GradReducer``, which packs it (pre-divided by the world size) into a flat bucket and launches
+``torch.distributed.all_reduce(bucket, async_op=True)`` -- RCCL on its own stream -- as soon as a bucket is full, while
+the backward kernels of earlier layers keep running.  The node's backward ends by waiting for the outstanding buckets.
+
+xGMI is point-to-point (7 links per GPU): a ring all-reduce is bound by one link, so buckets are large (64 MiB default:
+few, long transfers; 3.44 GB of float32 gradients = 52 buckets) and there is no attempt to mimic NCCL/NVSwitch tuning.
+
+``DataParallel`` is the module-level wrapper (``.module``, ``no_sync()``, same ``forward``); with gradient accumulation
+the unsynchronised micro-batches accumulate in ``.grad`` locally and the synchronising backward reduces the sum.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class GradReducer:
+    """Flat-bucket gradient averaging across a process group, fed in gradient-arrival order.
+
+    Bucket layout is fixed by the order in which gradients arrive during the first synchronised backward (identical on
+    every rank: the schedule is deterministic), like DDP's bucket rebuild; that first pass reduces bucket by bucket at
+    the end, later passes overlap."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], process_group=None, bucket_bytes: int = 64 << 20):
+        self.params = params                      # name -> nn.Parameter
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_bytes = int(bucket_bytes)
+        self.order: List[str] = []                # arrival order (first pass)
+        self.slot: Dict[str, tuple] = {}          # name -> (bucket index, offset, numel)
+        self.buckets: List[torch.Tensor] = []
+        self.fill: List[int] = []                 # elements received per bucket in the current pass
+        self.size: List[int] = []
+        self.handles: List = []
+        self.pending: Dict[str, torch.Tensor] = {}
+        self.launched = 0                         # collectives launched in the current pass (tests / bench)
+
+    # -------------------------------------------------------------------------------------------- layout
+    def _build(self, device, dtype):
+        cur, cur_elems = [], 0
+        groups = []
+        for name in self.order:
+            n = self.params[name].numel()
+            if cur and (cur_elems + n) * 4 > self.bucket_bytes:
+                groups.append(cur)
+                cur, cur_elems = [], 0
+            cur.append(name)
+            cur_elems += n
+        if cur:
+            groups.append(cur)
+        for bi, names in enumerate(groups):
+            off = 0
+            for name in names:
+                n = self.params[name].numel()
+                self.slot[name] = (bi, off, n)
+                off += (n + 63) // 64 * 64        # 256-byte aligned slices
+            self.buckets.append(torch.zeros(off, dtype=dtype, device=device))
+            self.size.append(len(names))
+        self.fill = [0] * len(self.buckets)
+
+    # ---------------------------------------------------------------------------------------------- pass
+    def begin(self):
+        self.handles, self.pending, self.launched = [], {}, 0
+        self.fill = [0] * len(self.buckets)
+
+    def put(self, name: str, g: torch.Tensor) -> torch.Tensor:
+        """Takes this rank's finished gradient of parameter ``name``; returns the tensor that will hold the average
+        once ``finish()`` has run."""
+        p = self.params[name]
+        g = g.reshape(p.shape)                     # 1x1 conv filters arrive as matrices
+        acc = p.grad                               # micro-batches accumulated under no_sync()
+        if acc is not None:
+            p.grad = None                          # the reduced sum becomes the gradient of this backward
+        if not self.slot:                          # first pass: record the order, reduce at the end
+            self.order.append(name)
+            g = g.to(torch.float32)
+            self.pending[name] = g if acc is None else g + acc.to(torch.float32)
+            return self.pending[name]
+        if name not in self.slot:                  # a parameter that had no gradient in the first pass
+            g = g.to(torch.float32)
+            self.pending[name] = (g if acc is None else g + acc.to(torch.float32)) * (1.0 / self.world)
+            return self.pending[name]
+        bi, off, n = self.slot[name]
+        view = self.buckets[bi][off:off + n].view(g.shape)
+        if acc is None:
+            torch.mul(g, 1.0 / self.world, out=view)
+        else:
+            torch.add(g, acc, out=view)
+            view.mul_(1.0 / self.world)
+        self.fill[bi] += 1
+        if self.fill[bi] == self.size[bi]:
+            self._launch(bi)
+        return view
+
+    def _launch(self, bi: int):
+        self.launched += 1
+        if self.world > 1:
+            self.handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self) -> Dict[str, torch.Tensor]:
+        """Completes the pass: after this the tensors returned by put() hold the averaged gradients (stream-ordered on
+        the current stream).  Returns replacements for first-pass gradients (which were not bucket views yet)."""
+        replaced: Dict[str, torch.Tensor] = {}
+        if not self.slot and self.order:
+            any_g = next(iter(self.pending.values()))
+            self._build(any_g.device, torch.float32)
+            for name in self.order:
+                bi, off, n = self.slot[name]
+                view = self.buckets[bi][off:off + n].view(self.pending[name].shape)
+                torch.mul(self.pending[name], 1.0 / self.world, out=view)
+                replaced[name] = view
+            self.pending = {}
+            for bi in range(len(self.buckets)):
+                self._launch(bi)
+        else:
+            for bi in range(len(self.buckets)):   # parameters without a gradient this pass leave a bucket short
+                if 0 < self.fill[bi] < self.size[bi]:
+                    self._launch(bi)
+            for name in sorted(self.pending):      # strays (see put): one small collective each, same order everywhere
+                self.launched += 1
+                if self.world > 1:
+                    self.handles.append(dist.all_reduce(self.pending[name], group=self.group, async_op=True))
+            self.pending = {}
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        return replaced
+
+
+class DataParallel(nn.Module):
+    """Drop-in for the DDP wrap accelerate applies to the UNet: ``DataParallel(unet)(sample, t, ctx)``; gradients in
+    ``unet.parameters()`` after ``loss.backward()`` are the average over the process group."""
+
+    def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 64.0):
+        super().__init__()
+        self.module = module
+        self.reducer = GradReducer(dict(module.named_parameters()), process_group, int(bucket_mb * (1 << 20)))
+        self.require_sync = True
+        if dist.is_initialized() and dist.get_world_size(process_group) > 1:
+            with torch.no_grad():                  # replicas start from rank 0's weights, as DDP's constructor does
+                for p in module.parameters():
+                    dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group else 0,
+                                   group=process_group)
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (train_latent_diffusion.py:1032): backward passes inside do not communicate."""
+        old, self.require_sync = self.require_sync, False
+        try:
+            yield
+        finally:
+            self.require_sync = old
+
+    def forward(self, *args, **kwargs):
+        self.module._ldm_grad_sink = self.reducer if self.require_sync else None
+        try:
+            return self.module(*args, **kwargs)
+        finally:
+            self.module._ldm_grad_sink = None

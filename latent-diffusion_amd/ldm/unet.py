@@ -464,6 +464,7 @@ class UNet(_HipModule):
         return ops.conv_out(h, P["final_conv.2.w"], P["final_conv.2.b"], dt)
 
     def _train_form(self, dt, t, needs, sample, encoder_hidden_states):
-        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1])
+        T = _train.Tape(self._packed_for(dt, train=True), dt, need_ctx_grad=needs[1],
+                        sink=getattr(self, "_ldm_grad_sink", None))
         out, b = _train.unet_train(T, self, sample, t, encoder_hidden_states.to(dt).contiguous(), needs[0])
         return out, (lambda dout: (b(dout), T.dctx)), T
