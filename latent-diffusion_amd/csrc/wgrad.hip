@@ -33,8 +33,9 @@ struct WgradParams {
   int ksize, stride, upsample;
   int M, N, K;
   int tiles_n, tiles_k;
-  int steps_per_split;     // 64-row steps per blockIdx.y
+  int steps_per_split;     // steps (64 rows; 32 for the large-tile kernel) per blockIdx.y
   int splits;
+  int cfg;                 // 0: 128x128 kernel; 1: <256,256>, 2: <320,256>, 3: <256,320> large tiles
 };
 
 __device__ __forceinline__ void wg_dma16(const void* base, unsigned bytes, unsigned char* lds, unsigned voff, unsigned soff) {
@@ -47,6 +48,9 @@ constexpr int WG_ROWB = 256;                              // bytes per LDS row o
 constexpr int WG_IMG = WG_MS * WG_ROWB;                   // 16 KiB per image
 constexpr int WG_STAGE = 2 * WG_IMG;                      // dY image then A image
 
+// TWO_SRC: the A operand is a two-source concat.  Compile-time, because the buffer descriptor of a lane's chunk would
+// otherwise be lane-dependent and every LDS-DMA would sit in a readfirstlane waterfall loop.
+template <bool TWO_SRC>
 __global__ void __launch_bounds__(256, 2)
 conv_wgrad_bf16_kernel(const WgradParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -86,7 +90,7 @@ conv_wgrad_bf16_kernel(const WgradParams p) {
     int c = kg - tap * p.ctot;
     a_kh[par] = tap / p.ksize;
     a_kw[par] = tap - a_kh[par] * p.ksize;
-    a_second[par] = c >= p.c0;
+    a_second[par] = TWO_SRC && c >= p.c0;
     if (a_second[par]) c -= p.c0;
     a_coff[par] = c;
     a_cs[par] = a_second[par] ? p.c1 : p.c0;
@@ -124,7 +128,7 @@ conv_wgrad_bf16_kernel(const WgradParams p) {
       const bool ok = a_kok[par] && m < (unsigned)p.M && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
       if (p.upsample) { ih >>= 1; iw >>= 1; }
       const unsigned avo = ok ? ((unsigned)((r_b[j] * p.hin + ih) * p.win + iw) * a_cs[par] + a_coff[par]) * 2u : OOB;
-      if (a_second[par]) wg_dma16(p.a1, bytes_a1, sa + piece * 1024, avo, 0);
+      if (TWO_SRC && a_second[par]) wg_dma16(p.a1, bytes_a1, sa + piece * 1024, avo, 0);
       else wg_dma16(p.a0, bytes_a0, sa + piece * 1024, avo, 0);
       // advance this piece's rows by one step
       r_ow[j] += d_ow;
@@ -152,30 +156,34 @@ conv_wgrad_bf16_kernel(const WgradParams p) {
     const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4_t*)a1);
     return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
-  auto compute = [&](int buf) {
-    const unsigned char* sdy = smem + buf * WG_STAGE;
-    const unsigned char* sa = sdy + WG_IMG;
-#pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      bf16x8_t fn[4], fk[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fn[i] = frag(sdy, wn * 4 + i, st);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fk[j] = frag(sa, wk * 4 + j, st);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[i], fk[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
+  // One step: all fragments of this step's images go to registers first, THEN the LDS-DMA of the next step is issued,
+  // then the MFMAs run with that DMA in flight.  (The compiler waits for every outstanding LDS-DMA in front of a
+  // transposed LDS read -- it cannot tell which image the DMA writes -- so DMA issued before the reads would be waited
+  // for at once and never overlap the math.)
   if (nsteps > 0) {
     stage(0, step_begin);
-    __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
+      __syncthreads();                                    // this step's images have landed; the other buffer is free
+      const unsigned char* sdy = smem + (s & 1) * WG_STAGE;
+      const unsigned char* sa = sdy + WG_IMG;
+      bf16x8_t fn[2][4], fk[2][4];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fn[st][i] = frag(sdy, wn * 4 + i, st);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fk[st][j] = frag(sa, wk * 4 + j, st);
+      }
+      __builtin_amdgcn_sched_barrier(0);
       if (s + 1 < nsteps) stage((s + 1) & 1, step_begin + s + 1);
-      compute(s & 1);
-      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fn[st][i], fk[st][j], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -195,18 +203,298 @@ conv_wgrad_bf16_kernel(const WgradParams p) {
     }
 }
 
-// dw[n][ci][tap] (+)= sum_s partial[s][n][tap*ctot + ci]   (fixed order; OIHW = the checkpoint layout)
+// ----------------------------------------------------------------------------------------------------------------
+// Large-tile kernel (the speed path).  The 128 x 128 tile above stages 64 flop per operand byte; the CU's L2->LDS path
+// delivers ~28 B/clk, so it cannot pass ~45 % of the matrix-core peak.  Here a workgroup of 8 waves owns a T0 (n) x T1 (k)
+// tile of dW with T0, T1 in {256, 320} (128-142 flop per staged byte; every N of the model is a multiple of 320 and so
+// are the K of its 1x1 layers), walks the pixels 32 rows per step -- one MFMA contraction block -- and keeps the LDS-DMA
+// of the next two steps in flight on a 3-slot ring with ONE barrier per step and counted vmcnt waits.  The transposed
+// fragment reads are issued as inline asm: in front of the builtin the compiler waits for every outstanding LDS-DMA (it
+// cannot tell which slot a DMA writes), which would serialise staging and math.
+constexpr int W2_MS = 32;
+
+// XOR swizzle of the 16-byte chunk index by row, chosen so that the 8 rows one 32-lane group of ds_read_b64_tr_b16
+// touches (32 bytes = one chunk PAIR per row) land in 8 different 32-byte bank slots of the 256-byte LDS word:
+//   512-byte rows (T = 256) all start at bank 0: flip the three pair bits with row & 7;
+//   640-byte rows (T = 320) alternate between the two 128-byte halves: flip two pair bits with (row >> 1) & 3
+//   (and stay inside aligned groups of 8 chunks: a row has 40).
+template <int T>
+__device__ __forceinline__ int w2_swz(int row) { return T == 256 ? (row & 7) << 1 : ((row >> 1) & 3) << 1; }
+
+// FAST: stride 1, no upsample, and (1x1 or power-of-two extents) -- the per-step address arithmetic described below is
+// compiled out of the other path entirely (its registers spilled, and every scratch reload waits for vmcnt(0), i.e. for
+// all LDS-DMA in flight).  Single source only: concat layers run as two passes (wgrad_two_pass).
+template <int T0, int T1, int W0, int W1, bool FAST>
+__global__ void __launch_bounds__(512)
+conv_wgrad_bf16_v2_kernel(const WgradParams p) {
+  constexpr bool TWO_SRC = false;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(W0 * W1 == 8, "8 waves");
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int F0 = T0 / W0 / 16, F1 = T1 / W1 / 16;     // 16-column fragments per wave along n and k
+  constexpr int CPR0 = T0 / 8, CPR1 = T1 / 8;             // 16-byte chunks per image row
+  constexpr int IMG0 = W2_MS * T0 * 2, IMG1 = W2_MS * T1 * 2;
+  constexpr int SLOT = IMG0 + IMG1;
+  constexpr int NI0 = IMG0 / 1024, NI1 = IMG1 / 1024, NI = NI0 + NI1;   // wave-wide DMA instructions per step
+  constexpr int JMAX = (NI + 7) / 8;
+  static_assert(IMG0 % 1024 == 0 && IMG1 % 1024 == 0, "whole DMA instructions");
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w0 = wave / W1, w1 = wave % W1;
+  const int tn = blockIdx.x % p.tiles_n, tk = blockIdx.x / p.tiles_n;
+  const int n0 = tn * T0, k0 = tk * T1;
+  const int total_steps = (p.M + W2_MS - 1) / W2_MS;
+  const int step_begin = blockIdx.y * p.steps_per_split;
+  const int nsteps = min(step_begin + p.steps_per_split, total_steps) - step_begin;
+
+  const unsigned bytes_a0 = (unsigned)p.batch * p.hin * p.win * p.c0 * 2u;
+  const unsigned bytes_a1 = (unsigned)p.batch * p.hin * p.win * (p.c1 ? p.c1 : p.c0) * 2u;
+  const unsigned bytes_dy = (unsigned)p.M * p.N * 2u;
+  const int hlim = p.upsample ? p.hin * 2 : p.hin, wlim = p.upsample ? p.win * 2 : p.win;
+  const int pad = p.ksize >> 1;
+  const float inv_w = 1.0f / (float)p.wout, inv_h = 1.0f / (float)p.hout;
+
+  // ---- static staging geometry: instruction q = j*8 + wave of a step moves chunks q'*64 .. +63 of one image
+  // (q' = q for the dY image, q - NI0 for the A image); lane -> (row, physical chunk); it fetches the logical chunk
+  // phys ^ (row & 7), so its column group is fixed for the whole kernel.
+  //
+  // The staging must cost (almost) no vector ALU: with ~45 VALU instructions per DMA the address arithmetic of two waves
+  // per SIMD took longer than the MFMAs.  So the buffer descriptors move instead of the lane offsets: per step the
+  // scalar unit advances the descriptor base by 32 rows and shrinks num_records (rows past M fall out of range and read
+  // zeros), and a lane's byte offset from that base is a kernel-long constant -- for dY outright, and for the im2col
+  // gather of a stride-1 layer too, because there input pixel = output pixel + (kh-1)*W + (kw-1) is linear in the row
+  // (base biased by W+1 pixels so the offset never goes negative).  Only the padding test of a 3x3 tap is per step:
+  // (oh, ow) of the row by shift/mask when W and H are powers of two (float reciprocals otherwise), two unsigned
+  // compares, one select.  Stride-2 and upsampled layers (six in the model) keep the general per-step arithmetic.
+  constexpr bool fast = FAST;                             // hout == hin, wout == win
+  const bool pow2 = FAST || ((p.wout & (p.wout - 1)) == 0 && (p.hout & (p.hout - 1)) == 0);
+  const int wlog = 31 - __builtin_clz(p.wout);
+  int s_row[JMAX];          // row of the step this lane stages in instruction j
+  unsigned s_col[JMAX];     // byte offset from the step's descriptor base (dY, fast A) or channel byte offset inside the
+                            // tap (general A); OOB when the column group lies past N / K
+  int s_tap[JMAX];          // A: kh | kw << 2 | second source << 4
+#pragma unroll
+  for (int j = 0; j < JMAX; ++j) {
+    const int q = j * 8 + wave;
+    const bool isA = q >= NI0;
+    const int c = (isA ? q - NI0 : q) * 64 + lane;
+    const int cpr = isA ? CPR1 : CPR0;
+    const int row = c / cpr, phys = c - row * cpr;
+    const int col = (phys ^ (isA ? w2_swz<T1>(row) : w2_swz<T0>(row))) * 8;
+    s_row[j] = row;
+    s_tap[j] = 0;
+    if (!isA) {
+      s_col[j] = n0 + col < p.N ? ((unsigned)row * p.N + n0 + col) * 2u : OOB;
+    } else {
+      const int k = k0 + col;
+      if (k < p.K) {
+        const int tap = k / p.ctot;
+        int ch = k - tap * p.ctot;
+        const int kh = tap / p.ksize, kw = tap - kh * p.ksize;
+        const bool second = TWO_SRC && ch >= p.c0;
+        if (second) ch -= p.c0;
+        const int cs = second ? p.c1 : p.c0;
+        s_tap[j] = kh | (kw << 2) | (second ? 16 : 0);
+        if (fast) s_col[j] = ((unsigned)(row + (kh - pad) * p.win + (kw - pad) + p.win + 1) * cs + ch) * 2u;
+        else s_col[j] = (unsigned)ch * 2u;
+      } else {
+        s_col[j] = OOB;
+      }
+    }
+  }
+  // first pixel of the current staging step as (sample, oh, ow): wave-uniform, advanced by 32 rows per staged step
+  // (general path and non-power-of-two extents only)
+  const int hw_out = p.hout * p.wout;
+  int g_b = 0, g_oh = 0, g_ow = 0;
+  if constexpr (!FAST) {
+    const long long m = (long long)step_begin * W2_MS;
+    g_b = (int)(m / hw_out);
+    const int rem = (int)(m - (long long)g_b * hw_out);
+    g_oh = rem / p.wout;
+    g_ow = rem - g_oh * p.wout;
+  }
+  const int d_ow = W2_MS % p.wout, d_ohr = W2_MS / p.wout;
+  const int d_oh = d_ohr % p.hout, d_b = d_ohr / p.hout;
+  const long long total_pix = (long long)p.batch * p.hin * p.win;
+
+  auto rsrc = [](const void* base, long long bytes) {
+    const int n = bytes < 0 ? 0 : bytes > 0x7fffffffLL ? 0x7fffffff : (int)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n, 0x00020000);
+  };
+  auto dma = [](__amdgpu_buffer_rsrc_t rs, unsigned char* lds, unsigned voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
+  };
+
+  auto stage = [&](int slot, int step) {
+    unsigned char* s0 = smem + slot * SLOT;
+    const long long row0 = (long long)step * W2_MS;       // uniform
+    const __amdgpu_buffer_rsrc_t rs_dy = rsrc(static_cast<const char*>(p.dy) + row0 * p.N * 2, (p.M - row0) * (long long)p.N * 2);
+    // fast path: base biased back by W+1 pixels (never dereferenced below the allocation: those lanes are padding)
+    const long long pix0 = row0 - p.win - 1;
+    const __amdgpu_buffer_rsrc_t rs_a0 = fast ? rsrc(static_cast<const char*>(p.a0) + pix0 * p.c0 * 2, (total_pix - pix0) * p.c0 * 2)
+                                              : rsrc(p.a0, bytes_a0);
+    const __amdgpu_buffer_rsrc_t rs_a1 = !TWO_SRC ? rs_a0
+                                         : fast ? rsrc(static_cast<const char*>(p.a1) + pix0 * p.c1 * 2, (total_pix - pix0) * p.c1 * 2)
+                                                : rsrc(p.a1, bytes_a1);
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int q = j * 8 + wave;
+      if (q >= NI) break;
+      if (q < NI0) {
+        dma(rs_dy, s0 + q * 1024, s_col[j]);
+        continue;
+      }
+      unsigned char* dst = s0 + IMG0 + (q - NI0) * 1024;
+      const int kh = s_tap[j] & 3, kw = (s_tap[j] >> 2) & 3;
+      const bool second = TWO_SRC && (s_tap[j] & 16);
+      unsigned vo;
+      if (fast && p.ksize == 1) {
+        vo = s_col[j];
+      } else {
+        int oh, ow, b = 0;
+        if (pow2) {
+          const int m = (int)row0 + s_row[j];
+          ow = m & (p.wout - 1);
+          oh = (m >> wlog) & (p.hout - 1);
+          if (!fast) b = m >> (wlog + (31 - __builtin_clz(p.hout)));
+        } else {    // exact float reciprocals: the operands are far below 2^20
+          const int pw = g_ow + s_row[j];
+          const int qw = (int)(((float)pw + 0.5f) * inv_w);
+          ow = pw - qw * p.wout;
+          const int ph = g_oh + qw;
+          const int qh = (int)(((float)ph + 0.5f) * inv_h);
+          oh = ph - qh * p.hout;
+          b = g_b + qh;
+        }
+        if (fast) {
+          const bool ok = (unsigned)(oh + kh - pad) < (unsigned)p.hin && (unsigned)(ow + kw - pad) < (unsigned)p.win;
+          vo = ok ? s_col[j] : OOB;
+        } else {
+          const unsigned m = (unsigned)row0 + s_row[j];
+          int ih = oh * p.stride - pad + kh, iw = ow * p.stride - pad + kw;
+          const bool ok = s_col[j] != OOB && m < (unsigned)p.M && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+          if (p.upsample) { ih >>= 1; iw >>= 1; }
+          const int cs = second ? p.c1 : p.c0;
+          vo = ok ? (unsigned)((b * p.hin + ih) * p.win + iw) * (unsigned)cs * 2u + s_col[j] : OOB;
+        }
+      }
+      if (second) dma(rs_a1, dst, vo);
+      else dma(rs_a0, dst, vo);
+    }
+    if constexpr (!FAST) {
+      g_ow += d_ow;
+      if (g_ow >= p.wout) { g_ow -= p.wout; g_oh += 1; }
+      g_oh += d_oh;
+      g_b += d_b;
+      if (g_oh >= p.hout) { g_oh -= p.hout; g_b += 1; }
+    }
+  };
+
+  f32x4_t acc[F0][F1];
+#pragma unroll
+  for (int i = 0; i < F0; ++i)
+#pragma unroll
+    for (int j = 0; j < F1; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // transposed fragment addresses: lane -> (row 4*fq + tq, chunk 2*ct + (tp >> 1), half (tp & 1)); the second read of a
+  // fragment is 16 rows further down, where (row + 16) & 7 == row & 7 leaves the swizzle unchanged
+  const int fr = lane & 15, fq = lane >> 4, tq = fr >> 2, tp = fr & 3;
+  const int frow = 4 * fq + tq;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned off0[F0], off1[F1];                            // byte offsets of this lane's fragments inside a slot
+#pragma unroll
+  for (int i = 0; i < F0; ++i) {
+    const int lchunk = 2 * ((w0 * F0 + i)) + (tp >> 1);
+    off0[i] = frow * (T0 * 2) + ((lchunk ^ w2_swz<T0>(frow)) << 4) + ((tp & 1) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < F1; ++j) {
+    const int lchunk = 2 * ((w1 * F1 + j)) + (tp >> 1);
+    off1[j] = IMG0 + frow * (T1 * 2) + ((lchunk ^ w2_swz<T1>(frow)) << 4) + ((tp & 1) << 3);
+  }
+
+  // this wave's DMA instructions per step (vmcnt counts them in issue order)
+  const int my_cnt = (NI - wave + 7) / 8;
+
+  if (nsteps > 0) {
+    stage(0, step_begin);
+    if (nsteps > 1) stage(1, step_begin + 1);
+    int slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+        if (my_cnt == JMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JMAX) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(JMAX - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                       // step s has landed for every wave; slot of step s-1 is free
+      asm volatile("" ::: "memory");
+      const unsigned sbase = lds_base + slot * SLOT;
+      bf16x4_t lo0[F0], hi0[F0], lo1[F1], hi1[F1];
+#pragma unroll
+      for (int i = 0; i < F0; ++i) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo0[i]) : "v"(sbase + off0[i]) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi0[i]) : "v"(sbase + off0[i]), "n"(16 * T0 * 2) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < F1; ++j) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo1[j]) : "v"(sbase + off1[j]) : "memory");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi1[j]) : "v"(sbase + off1[j]), "n"(16 * T1 * 2) : "memory");
+      }
+      if (s + 2 < nsteps) stage(slot == 0 ? 2 : slot - 1, step_begin + s + 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // tie every fragment to a point behind the wait (volatile asm keeps its order), so no MFMA can be moved above it
+#pragma unroll
+      for (int i = 0; i < F0; ++i) asm volatile("" : "+v"(lo0[i]), "+v"(hi0[i]));
+#pragma unroll
+      for (int j = 0; j < F1; ++j) asm volatile("" : "+v"(lo1[j]), "+v"(hi1[j]));
+      bf16x8_t f0[F0], f1[F1];
+#pragma unroll
+      for (int i = 0; i < F0; ++i) f0[i] = bf16x8_t{lo0[i][0], lo0[i][1], lo0[i][2], lo0[i][3], hi0[i][0], hi0[i][1], hi0[i][2], hi0[i][3]};
+#pragma unroll
+      for (int j = 0; j < F1; ++j) f1[j] = bf16x8_t{lo1[j][0], lo1[j][1], lo1[j][2], lo1[j][3], hi1[j][0], hi1[j][1], hi1[j][2], hi1[j][3]};
+      // the MFMAs must not be scheduled above the wait
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < F0; ++i)
+#pragma unroll
+        for (int j = 0; j < F1; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[i], f1[j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+
+  // ---- partial tile: C[row = n = fq*4 + r][col = k = fr]
+  float* out = p.partial + (size_t)blockIdx.y * p.N * p.K;
+#pragma unroll
+  for (int i = 0; i < F0; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + (w0 * F0 + i) * 16 + fq * 4 + r;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int j = 0; j < F1; ++j) {
+        const int k = k0 + (w1 * F1 + j) * 16 + fr;
+        if (k < p.K) out[(size_t)n * p.K + k] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[n][c_off + ci][tap] (+)= sum_s partial[s][n][tap*csrc + ci]   (fixed order; OIHW = the checkpoint layout).  A concat
+// layer's two sources are run as two passes: each fills its own channel range [c_off, c_off + csrc) of the ctot_dst channels.
 __global__ void __launch_bounds__(256)
-wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int K, int ctot, int taps, int splits,
-                  int accumulate) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over dw elements, OIHW order
+wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int K, int csrc, int taps, int splits,
+                  int accumulate, int c_off, int ctot_dst) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over this pass's dw elements, (n, ci, tap) order
   if (idx >= (long long)N * K) return;
   const int n = (int)(idx / K), rem = (int)(idx - (long long)n * K);
   const int ci = rem / taps, tap = rem - ci * taps;
-  const size_t src = (size_t)n * K + (size_t)tap * ctot + ci;
-  float v = accumulate ? dw[idx] : 0.f;
+  const size_t src = (size_t)n * K + (size_t)tap * csrc + ci;
+  const size_t dst = ((size_t)n * ctot_dst + c_off + ci) * taps + tap;
+  float v = accumulate ? dw[dst] : 0.f;
   for (int s = 0; s < splits; ++s) v += partial[(size_t)s * N * K + src];
-  dw[idx] = v;
+  dw[dst] = v;
 }
 
 
@@ -246,6 +534,20 @@ conv_wgrad_generic_kernel(const WgradParams p) {
   p.partial[(size_t)blockIdx.y * p.N * p.K + idx] = acc;
 }
 
+template <int T0, int T1, int W0, int W1, bool FAST>
+static int launch_wgrad_v2(const WgradParams& p, dim3 grid, hipStream_t st) {
+  constexpr int smem = 3 * W2_MS * (T0 + T1) * 2;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, FAST>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, FAST>), grid, dim3(512), smem, st, p);
+  return LDM_OK;
+}
+
 static bool wgrad_use_mfma(const LdmConvGemm* d) {
   return d->dtype == LDM_BF16 && (d->c0 + d->c1) % 8 == 0 && d->c0 % 8 == 0 && d->n % 8 == 0;
 }
@@ -263,6 +565,28 @@ static void wgrad_plan(const LdmConvGemm* d, WgradParams& p) {
     p.steps_per_split = 0;
     return;
   }
+  p.cfg = 0;
+  if (!getenv("LDM_WGRAD_V1") && d->c1 == 0) {   // (a concat with c1 % 8 != 0 stays on the 128x128 kernel)
+    // large tiles: the shape with the least padded work; one workgroup per CU, so aim at one full round of 256
+    static const int shapes[3][2] = {{256, 256}, {320, 256}, {256, 320}};
+    long long best = -1;
+    // the 320-wide tiles of the general (strided / upsampled / non-power-of-two) path would spill: 256 x 256 there
+    const bool pow2 = (d->wout & (d->wout - 1)) == 0 && (d->hout & (d->hout - 1)) == 0;
+    const bool fastk = d->stride == 1 && !d->upsample && (d->ksize == 1 || pow2);
+    for (int c = 0; c < (fastk ? 3 : 1); ++c) {
+      const long long tn = (p.N + shapes[c][0] - 1) / shapes[c][0], tk = (p.K + shapes[c][1] - 1) / shapes[c][1];
+      const long long padded = tn * shapes[c][0] * tk * shapes[c][1];
+      if (best < 0 || padded < best) { best = padded; p.cfg = c + 1; p.tiles_n = (int)tn; p.tiles_k = (int)tk; }
+    }
+    const int steps = (p.M + W2_MS - 1) / W2_MS;
+    const int tiles = p.tiles_n * p.tiles_k;
+    int splits = tiles >= 256 ? 1 : 256 / tiles;
+    if (splits > steps / 16) splits = steps / 16;
+    if (splits < 1) splits = 1;
+    p.steps_per_split = (steps + splits - 1) / splits;
+    p.splits = (steps + p.steps_per_split - 1) / p.steps_per_split;
+    return;
+  }
   const int steps = (p.M + WG_MS - 1) / WG_MS;
   // enough workgroups for two per CU, at least 8 steps each
   int splits = (512 + p.tiles_n * p.tiles_k - 1) / (p.tiles_n * p.tiles_k);
@@ -277,8 +601,27 @@ static void wgrad_plan(const LdmConvGemm* d, WgradParams& p) {
 
 using namespace ldm;
 
+// A concat layer on the matrix-core path runs as two single-source passes (a lane-dependent source would put every
+// LDS-DMA of the gather into a readfirstlane waterfall loop).
+static bool wgrad_two_pass(const LdmConvGemm* d) { return d->c1 > 0 && wgrad_use_mfma(d) && d->c1 % 8 == 0 && !getenv("LDM_WGRAD_V1"); }
+
+static LdmConvGemm wgrad_source(const LdmConvGemm* d, int which) {
+  LdmConvGemm s = *d;
+  if (which == 1) { s.a0 = d->a1; s.c0 = d->c1; }
+  s.a1 = nullptr; s.c1 = 0;
+  return s;
+}
+
+static int wgrad_run(const LdmConvGemm* d, const void* dy, float* dw, int accumulate, void* workspace, long long workspace_bytes,
+                     void* stream, int c_off, int ctot_dst);
+
 extern "C" long long ldm_conv_wgrad_workspace_bytes(const LdmConvGemm* d) {
   if (!d || d->batch <= 0) return 0;
+  if (wgrad_two_pass(d)) {
+    const LdmConvGemm s0 = wgrad_source(d, 0), s1 = wgrad_source(d, 1);
+    const long long b0 = ldm_conv_wgrad_workspace_bytes(&s0), b1 = ldm_conv_wgrad_workspace_bytes(&s1);
+    return b0 > b1 ? b0 : b1;
+  }
   WgradParams p;
   wgrad_plan(d, p);
   return (long long)p.splits * p.N * p.K * 4;
@@ -286,6 +629,19 @@ extern "C" long long ldm_conv_wgrad_workspace_bytes(const LdmConvGemm* d) {
 
 extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, int accumulate, void* workspace,
                               long long workspace_bytes, void* stream) {
+  LDM_REQUIRE(d != nullptr, "ldm_conv_wgrad: null descriptor");
+  if (d->batch > 0 && wgrad_two_pass(d)) {
+    LDM_REQUIRE(d->a1 != nullptr, "ldm_conv_wgrad: null pointer");
+    const LdmConvGemm s0 = wgrad_source(d, 0), s1 = wgrad_source(d, 1);
+    int rc = wgrad_run(&s0, dy, dw, accumulate, workspace, workspace_bytes, stream, 0, d->c0 + d->c1);
+    if (rc) return rc;
+    return wgrad_run(&s1, dy, dw, accumulate, workspace, workspace_bytes, stream, d->c0, d->c0 + d->c1);
+  }
+  return wgrad_run(d, dy, dw, accumulate, workspace, workspace_bytes, stream, 0, d->c0 + d->c1);
+}
+
+static int wgrad_run(const LdmConvGemm* d, const void* dy, float* dw, int accumulate, void* workspace, long long workspace_bytes,
+                     void* stream, int c_off, int ctot_dst) {
   LDM_REQUIRE(d != nullptr, "ldm_conv_wgrad: null descriptor");
   LDM_REQUIRE(dtype_ok(d->dtype), "ldm_conv_wgrad: bad dtype %d", d->dtype);
   LDM_REQUIRE(d->ksize == 1 || d->ksize == 3, "ldm_conv_wgrad: ksize must be 1 or 3 (got %d)", d->ksize);
@@ -304,7 +660,7 @@ extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, i
   hipStream_t st = (hipStream_t)stream;
   if (d->batch == 0) {
     if (!accumulate) {
-      hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.N * p.K * 4, st);
+      hipError_t e = hipMemsetAsync(dw, 0, (size_t)p.N * p.K * 4, st);   // (batch 0 never takes the two-pass route)
       if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipMemsetAsync: %s", hipGetErrorString(e)); return LDM_EHIP; }
     }
     return LDM_OK;
@@ -326,12 +682,27 @@ extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, i
     const int smem = 2 * WG_STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
       if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
       attr_done = true;
     }
     dim3 grid(p.tiles_n * p.tiles_k, p.splits);
-    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), smem, st, p);
+    if (p.cfg != 0) {
+      int rc = LDM_OK;
+      const bool pow2 = (d->wout & (d->wout - 1)) == 0 && (d->hout & (d->hout - 1)) == 0;
+      const bool fastk = d->stride == 1 && !d->upsample && (d->ksize == 1 || pow2);
+      switch (p.cfg * 2 + (fastk ? 1 : 0)) {
+        case 2: rc = launch_wgrad_v2<256, 256, 2, 4, false>(p, grid, st); break;
+        case 3: rc = launch_wgrad_v2<256, 256, 2, 4, true>(p, grid, st); break;
+        case 5: rc = launch_wgrad_v2<320, 256, 2, 4, true>(p, grid, st); break;
+        case 7: rc = launch_wgrad_v2<256, 320, 4, 2, true>(p, grid, st); break;
+        default: set_error("ldm_conv_wgrad: internal: tile %d without the fast path", p.cfg); return LDM_EINVAL;
+      }
+      if (rc) return rc;
+    } else if (d->c1) hipLaunchKernelGGL(conv_wgrad_bf16_kernel<true>, grid, dim3(256), smem, st, p);
+    else hipLaunchKernelGGL(conv_wgrad_bf16_kernel<false>, grid, dim3(256), smem, st, p);
   } else {
     dim3 grid((unsigned)(((long long)p.N * p.K + 255) / 256), p.splits);
     if (d->dtype == LDM_BF16) hipLaunchKernelGGL((conv_wgrad_generic_kernel<bf16_t>), grid, dim3(256), 0, st, p);
@@ -340,7 +711,7 @@ extern "C" int ldm_conv_wgrad(const LdmConvGemm* d, const void* dy, float* dw, i
   LDM_HIP_CHECK_LAUNCH("ldm_conv_wgrad");
   const long long total = (long long)p.N * p.K;
   hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot,
-                     d->ksize * d->ksize, p.splits, accumulate);
+                     d->ksize * d->ksize, p.splits, accumulate, c_off, ctot_dst);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_wgrad(fold)");
   return LDM_OK;
 }
