@@ -256,15 +256,16 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
 
 // --------------------------------------------------------------------------------------- dK, dV
 template <int D>
-__global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
+__global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1))
 attn_bwd_dkv_kernel(const AttnBwdParams p) {
   using G = AbGeom<D>;
+  constexpr int NG = D > 40 ? 1 : 2;      // 16-key groups per wave: one for the wide heads (the dK/dV accumulators of two would spill)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x (Q image, dO image, L[64], Dl[64])
   constexpr int BUF = 2 * G::IMG + 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int k0 = blockIdx.x * (64 * NG) + wave * (16 * NG);
   const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
   const bf16_t* gp = static_cast<const bf16_t*>(p.d_o) + (size_t)b * p.lq * p.do_stride + h * D;
   const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
@@ -278,16 +279,16 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
 
   for (int i = tid * 16; i < G::NBUF * BUF; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
 
-  bf16x8_t kf[2][G::KS], vf[2][G::KS];
+  bf16x8_t kf[NG][G::KS], vf[NG][G::KS];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int ki = k0 + g * 16 + fr;
     ab_load_bfrag<D>(kp, ki, p.lk, p.kv_stride, fq, kf[g]);
     ab_load_bfrag<D>(vp, ki, p.lk, p.kv_stride, fq, vf[g]);
   }
-  f32x4_t dk[2][G::DT], dv[2][G::DT];
+  f32x4_t dk[NG][G::DT], dv[NG][G::DT];
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+  for (int g = 0; g < NG; ++g)
 #pragma unroll
     for (int t = 0; t < G::DT; ++t) { dk[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
 
@@ -330,7 +331,7 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     const float* lt = reinterpret_cast<const float*>(cur + 2 * G::IMG);
     const float* dlt = reinterpret_cast<const float*>(cur + 2 * G::IMG + 256);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NG; ++g) {
       // S[query rows qb*16 + fq*4 + r][key column fr] and dP alike
       float pv[4][4], ds[4][4];
 #pragma unroll
@@ -369,7 +370,7 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     }
   }
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NG; ++g) {
     const int ki = k0 + g * 16 + fr;
     if (ki >= p.lk) continue;
 #pragma unroll
@@ -406,7 +407,7 @@ static int launch_attn_bwd(const AttnBwdParams& p, hipStream_t st) {
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(prep)");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3((p.lq + 127) / 128, p.heads, p.batch), dim3(256), smem_dq, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dq)");
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((p.lk + 127) / 128, p.heads, p.batch), dim3(256), smem_dkv, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((p.lk + (D > 40 ? 63 : 127)) / (D > 40 ? 64 : 128), p.heads, p.batch), dim3(256), smem_dkv, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dkv)");
   return LDM_OK;
 }
