@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="latents per GPU (default: the metric's 32)")
+    ap.add_argument("--latent", type=int, default=LATENT, help="latent extent (default 64: the metric's; 96 = BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -112,10 +113,16 @@ def main():
     sched.set_timesteps(50, device=dev)
 
     B = args.batch
+    LAT = args.latent
+    if LAT == 64:
+        flops_per_image = FLOPS_PER_IMAGE_64
+    else:   # algorithmic FLOPs of another extent: the oracle's shape walk (host arithmetic only, nothing is executed)
+        from oracle import unet_ref as uref
+        flops_per_image = uref.flops_per_image(uref.UNetConfig(), LAT, LAT)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)  # every rank owns different latents (batch shard)
-    lat0 = torch.randn(B, 4, LATENT, LATENT, device=dev, generator=gen)
+    lat0 = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
     ctx = torch.randn(B, CTX_LEN, CTX_DIM, device=dev, generator=gen).bfloat16()
-    noise = torch.randn(B, 4, LATENT, LATENT, device=dev, generator=gen)
+    noise = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
     ts = sched.timesteps
 
     def one_step(lat, i):
@@ -163,16 +170,17 @@ def main():
         n_l, fl, tt = per[dom]
         achieved = fl / tt
         out = {
-            "metric": "UNet denoise img-steps/sec at 64x64 latents",
+            "metric": f"UNet denoise img-steps/sec at {LAT}x{LAT} latents",
             "value": round(value, 2), "unit": "img-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SD-1.5-shaped UNet (859.5M params, random init) bf16 forward + DDPM scheduler step, "
-                                   f"batch {B} of 4x64x64 latents + 77x768 context per GPU (BASELINE.json configs[1])",
-                       "per_gpu_batch": B, "global_batch": B * world, "latent": "4x64x64",
+                                   f"batch {B} of 4x{LAT}x{LAT} latents + 77x768 context per GPU "
+                                   + ("(BASELINE.json configs[1])" if LAT == 64 and B == BATCH else "(non-headline shape)"),
+                       "per_gpu_batch": B, "global_batch": B * world, "latent": f"4x{LAT}x{LAT}",
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
-                       "end_to_end_tflops_per_gpu": round(FLOPS_PER_IMAGE_64 * B / (elapsed / args.steps) / 1e12, 1),
-                       "end_to_end_frac_of_mfma_peak": round(FLOPS_PER_IMAGE_64 * B / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
+                       "end_to_end_tflops_per_gpu": round(flops_per_image * B / (elapsed / args.steps) / 1e12, 1),
+                       "end_to_end_frac_of_mfma_peak": round(flops_per_image * B / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
                        "gemm_kernel_share_of_step": round(gemm_time / elapsed, 3)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": None,
@@ -181,7 +189,7 @@ def main():
                          "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                                   "avg_us": round(1e6 * v[2] / v[0], 1)} for k, v in sorted(per.items())}},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and LAT == 64:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -245,3 +245,18 @@ def test_sampling_with_guidance_matches_manual_loop():
             eps = eps_u + 7.5 * (eps_c - eps_u)
             lat = sch.step(eps, t, lat, noise=sampling.global_noise(9, i, (2, 4, 16, 16), 0, 2, torch.device("cuda"))).prev_sample
     assert rel_l2(got, lat) < 1e-4
+
+
+def test_small_unet_non_power_of_two_latents():
+    """24x24 latents (levels 24, 12, 6, 3 -- the 96x96 latents of BASELINE configs[4] give 96, 48, 24, 12): extents that
+    are not powers of two through every kernel's index arithmetic, float32 against the float64 oracle."""
+    net, cfg, sd = _small_unet()
+    x, ctx = seeded((2, 4, 24, 24), 91), seeded((2, 77, 768), 92)
+    t = torch.tensor([7, 650])
+    with torch.no_grad():
+        y = net(x.cuda(), t.cuda(), ctx.cuda())
+        ref = uref.unet_forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), t, ctx.double())
+        yb = net(x.cuda().bfloat16(), t.cuda(), ctx.cuda().bfloat16())
+    assert y.shape == x.shape
+    assert rel_l2(y, ref) < 1e-4
+    assert torch.isfinite(yb.float()).all()

@@ -31,7 +31,8 @@ CASES = [  # name, (H, W, C0, C1), N, ksize, stride, up, glu
 
 
 def main():
-    sel = [a for a in sys.argv[1:] if not a.startswith("--")]
+    skip = {i + 1 for i, a in enumerate(sys.argv) if a in ("--iters", "--tile")}
+    sel = [a for i, a in enumerate(sys.argv) if i >= 1 and not a.startswith("--") and i not in skip]
     iters = 20
     if "--iters" in sys.argv:
         iters = int(sys.argv[sys.argv.index("--iters") + 1])
@@ -40,6 +41,8 @@ def main():
     tiles = [None]
     if "--sweep" in sys.argv:   # every BK=64 tile the library instantiates, forced through LDM_GEMM_TILE
         tiles = [None, "64,128", "64,160", "128,128", "128,160", "256,128", "256,160"]
+    if "--tile" in sys.argv:    # auto against one forced tile
+        tiles = [None, sys.argv[sys.argv.index("--tile") + 1]]
     if "--splits" in sys.argv:  # split-K variants (only honoured for small-M cases, where ops lends the workspace)
         tiles = [None, "64,128", "64,128,2", "64,128,3", "128,128,2", "128,128,3", "128,128,4", "128,160,2", "128,160,4",
                  "128,160,6", "256,160,4", "256,160,8"]
