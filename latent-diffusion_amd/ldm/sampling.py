@@ -43,15 +43,31 @@ def global_noise(seed: int, step: int, shape, lo: int, hi: int, device, dtype=to
 def sample_latents(denoiser: Callable, scheduler, ctx: torch.Tensor, *, latent_shape=(4, 64, 64),
                    num_inference_steps: int = 50, guidance_scale: Optional[float] = None,
                    uncond_ctx: Optional[torch.Tensor] = None, seed: int = 0, rank: int = 0, world: int = 1,
-                   device=None, latent_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+                   device=None, latent_dtype: torch.dtype = torch.float32, micro_batch: Optional[int] = None) -> torch.Tensor:
     """Run the reverse loop for this rank's shard of the batch and return its final latents (hi-lo, C, H, W).
 
     ctx: (N, S, D) conditioning of the WHOLE batch (each rank slices its rows).  With ``guidance_scale`` the
     denoiser sees [latents, latents] with [uncond_ctx, ctx] exactly as the reference does (:581, :561) and the
     combine eps_u + g (eps_c - eps_u) (:592) runs inside the scheduler's fused step kernel.
+    micro_batch: run the shard as independent chunks of at most this many latents (each through all steps); the result
+    is the same, the activations stay small (a 256-latent shard in one batch would pass the kernels' 2 GiB operands).
     """
     n = ctx.shape[0]
     lo, hi = shard_range(n, rank, world)
+    if micro_batch is not None and hi - lo > micro_batch:
+        parts = []
+        for c0 in range(lo, hi, micro_batch):
+            parts.append(_sample_rows(denoiser, scheduler, ctx, c0, min(c0 + micro_batch, hi), latent_shape, num_inference_steps,
+                                      guidance_scale, uncond_ctx, seed, device, latent_dtype))
+        return torch.cat(parts, dim=0)
+    return _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_steps, guidance_scale, uncond_ctx, seed,
+                        device, latent_dtype)
+
+
+def _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_steps, guidance_scale, uncond_ctx, seed, device,
+                 latent_dtype):
+    """The reverse loop for global rows [lo, hi)."""
+    n = ctx.shape[0]
     device = device if device is not None else ctx.device
     my_ctx = ctx[lo:hi].to(device)
     scheduler.set_timesteps(num_inference_steps, device=device)

@@ -106,3 +106,15 @@ def test_two_gloo_ranks_match_one_process(tmp_path, guidance):
     full = torch.load(os.path.join(str(tmp_path), "full.pt"), weights_only=True)
     assert full.shape == ref.shape
     assert torch.equal(full, ref)
+
+
+def test_micro_batches_match_the_whole_shard():
+    from ldm import sampling
+    g = torch.Generator().manual_seed(7)
+    ctx = torch.randn(7, 5, 8, generator=g)
+    kw = dict(latent_shape=(4, 6, 6), num_inference_steps=4, seed=3, device=torch.device("cpu"))
+    whole = sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, **kw)
+    for mb in (1, 3, 7, 100):
+        assert torch.equal(sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, micro_batch=mb, **kw), whole)
+    part = sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, rank=1, world=2, micro_batch=2, **kw)
+    assert torch.equal(part, whole[4:])
