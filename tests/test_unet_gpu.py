@@ -260,3 +260,35 @@ def test_small_unet_non_power_of_two_latents():
     assert y.shape == x.shape
     assert rel_l2(y, ref) < 1e-4
     assert torch.isfinite(yb.float()).all()
+
+
+def test_graph_replay_matches_eager():
+    """ldm/graph.GraphedUNet (hipGraph capture of one forward): replays reproduce the eager forward bit for bit, for new
+    inputs and timesteps, in float32 and bf16, and the graph is re-captured when the weights change."""
+    from ldm.graph import GraphedUNet
+    net, _, _ = _small_unet()
+    x, ctx = seeded((2, 4, 16, 16), 93).cuda(), seeded((2, 77, 768), 94).cuda()
+    for dt in (torch.float32, torch.bfloat16):
+        gnet = GraphedUNet(net, batch=2, latent_hw=(16, 16), sample_dtype=torch.float32, compute_dtype=dt)
+        for k, t in enumerate((torch.tensor([5, 900], device="cuda"), 37, torch.tensor(640, device="cuda"))):
+            xs = x + k
+            with torch.no_grad():
+                if dt == torch.bfloat16:
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        ref = net(xs, t, ctx.bfloat16())
+                else:
+                    ref = net(xs, t, ctx)
+            got = gnet(xs, t, ctx.to(dt)).clone()
+            assert got.dtype == ref.dtype and torch.equal(got, ref), (dt, k)
+    with torch.no_grad():
+        net.conv_in.bias.add_(0.25)
+        ref = net(x, 11, ctx)
+    assert torch.equal(gnet.__class__(net, 2, (16, 16), compute_dtype=torch.float32)(x, 11, ctx), ref)
+    g32 = GraphedUNet(net, batch=2, latent_hw=(16, 16), compute_dtype=torch.float32)
+    first = g32(x, 11, ctx).clone()
+    with torch.no_grad():
+        net.conv_in.bias.add_(0.25)
+        ref2 = net(x, 11, ctx)
+    assert torch.equal(g32(x, 11, ctx), ref2) and not torch.equal(first, ref2)
+    with pytest.raises(ValueError):
+        g32(x[:1], 11, ctx[:1])
