@@ -94,6 +94,14 @@ int ldm_ddpm_add_noise(const void* x0, const void* noise, float* out, int dtype,
 int ldm_pack_weight(const float* src, void* dst, int dst_dtype, int cout, int cin, int kh, int kw,
                     int glu_pairs, void* stream);
 
+/* Both derived layouts of one filter in one pass: fwd = ldm_pack_weight's [o'][kh][kw][ci] (may be NULL) and dgrad =
+ * [ci][kh][kw][o'] with the taps rotated by 180 degrees and row pitch dgrad_ld >= cout (may be NULL): the filter with which
+ * ldm_conv_gemm on dY computes the input gradient of the layer (autograd of nn.Conv2d / nn.Linear under loss.backward(),
+ * train_latent_diffusion.py:1119).  Filters fused along the output dimension (q|k|v, the 22 time projections) are packed part
+ * by part: fwd at its row offset, dgrad at its column offset of one matrix of pitch dgrad_ld.  kh*kw <= 9. */
+int ldm_pack_weight_pair(const float* src, void* fwd, void* dgrad, int dst_dtype, int cout, int cin, int kh, int kw,
+                         int glu_pairs, long long dgrad_ld, void* stream);
+
 /* ------------------------------------------------------------------- UNet: implicit-GEMM conv/linear */
 
 enum {
@@ -223,6 +231,33 @@ long long ldm_layernorm_backward_workspace_floats(int cols);
 int ldm_layernorm_backward(const void* x, const void* dy, int dtype, long long rows, int cols, float eps, const float* gamma,
                            const void* add, void* dx, float* dgamma, float* dbeta, int accumulate, float* workspace,
                            void* stream);
+
+/* ------------------------------------------------------- training-step tail around the UNet
+ * Tensor lists are DEVICE tables: per tensor its pointers (as 64-bit integers), per chunk -- at most
+ * ldm_opt_chunk_elements() consecutive float32 elements of one tensor, one workgroup each -- the tensor index, the element
+ * offset inside the tensor and the length. */
+int ldm_opt_chunk_elements(void);
+
+/* out[0] = L2 norm over all gradients, out[1] = min(1, max_norm / (norm + 1e-6)) (max_norm <= 0: 1): the reduction of
+ * torch.nn.utils.clip_grad_norm_ (train_latent_diffusion.py:1123) without touching the gradients -- ldm_adamw_step applies the
+ * scale while it reads them.  partial: nchunks floats of DEVICE scratch.  Deterministic (fixed-order folds). */
+int ldm_grad_norm_clip(const unsigned long long* grads, int ntensors, const int* chunk_tensor, const long long* chunk_off,
+                       const int* chunk_len, int nchunks, float max_norm, float* partial, float* out, void* stream);
+
+/* One torch.optim.AdamW step (train_latent_diffusion.py:909-915, :1124: decoupled weight decay, bias correction, no amsgrad)
+ * over all tensors in one launch: p, exp_avg, exp_avg_sq updated in place from g * clip[1] (clip: DEVICE pointer to the pair
+ * written by ldm_grad_norm_clip, or NULL for no clipping).  step counts from 1.  float32 tensors; the hyper-parameters are
+ * doubles because torch derives 1 - beta, 1 - lr*wd and the bias corrections from Python floats before rounding. */
+int ldm_adamw_step(const unsigned long long* params, const unsigned long long* grads, const unsigned long long* exp_avg,
+                   const unsigned long long* exp_avg_sq, int ntensors, const int* chunk_tensor, const long long* chunk_off,
+                   const int* chunk_len, int nchunks, double lr, double beta1, double beta2, double eps, double weight_decay,
+                   long long step, const float* clip, void* stream);
+
+/* loss[0] = mean((pred - target)^2) in float32 (F.mse_loss(pred.float(), noise.float()), :1108) and, if dpred != NULL, its
+ * gradient dpred = 2 (pred - target) / n in pred's dtype, in the same pass.  workspace: ldm_mse_workspace_floats(n) floats. */
+long long ldm_mse_workspace_floats(long long n);
+int ldm_mse_loss(const void* pred, int dtype, const float* target, long long n, float* loss, void* dpred, float* workspace,
+                 void* stream);
 
 /* -------------------------------------------------------------------------------- UNet: attention */
 

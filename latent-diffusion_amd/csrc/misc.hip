@@ -25,6 +25,53 @@ pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout,
   }
 }
 
+// Both derived layouts of one filter from ONE coalesced read of the checkpoint tensor (training repacks every filter after
+// every optimizer step: 859.5 M floats):
+//   fwd  [o'][tap][ci]          (ldm_pack_weight's layout; o' = GLU-interleaved row order when glu)
+//   dgrad[ci][taps-1-tap][o']   row pitch dgrad_ld (>= cout: several filters may share one fused dgrad matrix): the filter of
+//                               the input-gradient pass -- in/out transposed, taps rotated by 180 degrees.
+// One workgroup moves a 32 (o') x 32 (ci) x taps block through LDS; global runs are 32 x taps floats in, 32 elements out.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad, int cout, int cin, int taps,
+                        int glu, long long dgrad_ld) {
+  extern __shared__ float tile[];                       // [32 o'][32*taps + 1]
+  const int ost = 32 * taps + 1;
+  const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int half = cout >> 1;
+  const int run = 32 * taps;                            // floats per source row segment
+  for (int i = threadIdx.x; i < 32 * run; i += 256) {
+    const int ol = i / run, k = i - ol * run;           // k = (ci_local, tap) flattened as in the source
+    const int op = o0 + ol;
+    const int ci = c0 + k / taps;
+    float v = 0.f;
+    if (op < cout && ci < cin) {
+      int o = op;
+      if (glu) { const int blk = op >> 5, w = op & 31; o = w < 16 ? blk * 16 + w : half + blk * 16 + (w - 16); }
+      v = src[((long long)o * cin + c0) * taps + k];
+    }
+    tile[ol * ost + k] = v;
+  }
+  __syncthreads();
+  if (fwd != nullptr) {
+    for (int i = threadIdx.x; i < 32 * run; i += 256) { // (o', tap, ci_local) order
+      const int ol = i / run, r = i - ol * run;
+      const int tap = r >> 5, cl = r & 31;
+      const int op = o0 + ol, ci = c0 + cl;
+      if (op < cout && ci < cin) Elem<T>::st(fwd + ((long long)op * taps + tap) * cin + ci, tile[ol * ost + cl * taps + tap]);
+    }
+  }
+  if (dgrad != nullptr) {
+    for (int i = threadIdx.x; i < 32 * run; i += 256) { // (ci_local, tap', o') order
+      const int ol = i & 31, r = i >> 5;
+      const int cl = r / taps, tp = r - cl * taps;
+      const int op = o0 + ol, ci = c0 + cl;
+      if (op < cout && ci < cin)
+        Elem<T>::st(dgrad + ((long long)ci * taps + tp) * dgrad_ld + op, tile[ol * ost + cl * taps + (taps - 1 - tp)]);
+    }
+  }
+}
+
 template <typename T>
 __global__ void timestep_embedding_kernel(const float* __restrict__ t, int batch, int dim, T* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,6 +223,28 @@ extern "C" int ldm_pack_weight(const float* src, void* dst, int dst_dtype, int c
   else
     hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, cout, cin, kh * kw, glu_pairs);
   LDM_HIP_CHECK_LAUNCH("ldm_pack_weight");
+  return LDM_OK;
+}
+
+extern "C" int ldm_pack_weight_pair(const float* src, void* fwd, void* dgrad, int dst_dtype, int cout, int cin, int kh, int kw,
+                                    int glu_pairs, long long dgrad_ld, void* stream) {
+  LDM_REQUIRE(dtype_ok(dst_dtype), "ldm_pack_weight_pair: bad dtype %d", dst_dtype);
+  LDM_REQUIRE(src && (fwd || dgrad), "ldm_pack_weight_pair: null pointer");
+  LDM_REQUIRE(cout >= 1 && cin >= 1 && kh >= 1 && kw >= 1 && kh * kw <= 9, "ldm_pack_weight_pair: bad sizes");
+  LDM_REQUIRE(!glu_pairs || cout % 32 == 0, "ldm_pack_weight_pair: glu_pairs needs cout %% 32 == 0 (got %d)", cout);
+  LDM_REQUIRE(dgrad == nullptr || dgrad_ld >= cout, "ldm_pack_weight_pair: dgrad row pitch %lld below cout %d", dgrad_ld, cout);
+  const int taps = kh * kw;
+  const dim3 grid((cout + 31) / 32, (cin + 31) / 32);
+  LDM_REQUIRE(grid.y <= 65535, "ldm_pack_weight_pair: cin too large");
+  const size_t smem = (size_t)32 * (32 * taps + 1) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dst_dtype == LDM_BF16)
+    hipLaunchKernelGGL((pack_weight_pair_kernel<bf16_t>), grid, dim3(256), smem, st, src, (bf16_t*)fwd, (bf16_t*)dgrad, cout, cin, taps,
+                       glu_pairs, dgrad_ld);
+  else
+    hipLaunchKernelGGL((pack_weight_pair_kernel<float>), grid, dim3(256), smem, st, src, (float*)fwd, (float*)dgrad, cout, cin, taps,
+                       glu_pairs, dgrad_ld);
+  LDM_HIP_CHECK_LAUNCH("ldm_pack_weight_pair");
   return LDM_OK;
 }
 

@@ -67,6 +67,12 @@ _SIGNATURES = {
     "ldm_colsum": [c_void_p, c_int, C.c_longlong, C.c_longlong, c_int, c_void_p, c_int, c_void_p, c_void_p],
     "ldm_glu_forward": [c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
     "ldm_glu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_int, c_int, c_void_p],
+    "ldm_opt_chunk_elements": [],
+    "ldm_grad_norm_clip": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, C.c_float, c_void_p, c_void_p, c_void_p],
+    "ldm_adamw_step": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, C.c_double, C.c_double,
+                       C.c_double, C.c_double, C.c_double, C.c_longlong, c_void_p, c_void_p],
+    "ldm_mse_loss": [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p],
+    "ldm_pack_weight_pair": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.c_longlong, c_void_p],
     "ldm_add": [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_int, C.c_longlong, c_int, c_void_p],
     "ldm_silu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_void_p],
     "ldm_groupnorm_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -99,6 +105,7 @@ _LONGLONG_QUERIES = {
     "ldm_colsum_workspace_floats": [C.c_longlong, c_int],
     "ldm_groupnorm_backward_workspace_floats": [c_int, c_int, c_int],
     "ldm_layernorm_backward_workspace_floats": [c_int],
+    "ldm_mse_workspace_floats": [C.c_longlong],
 }
 
 EXPORTED_SYMBOLS = (["ldm_abi_version", "ldm_last_error", "ldm_conv_wgrad_workspace_bytes"] + list(_SIGNATURES)

@@ -56,6 +56,39 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) ->
     return out
 
 
+def pack_weight_pair(w: torch.Tensor, dtype: torch.dtype, *, glu_pairs: bool = False, fwd: Optional[torch.Tensor] = None,
+                     dgrad: Optional[torch.Tensor] = None, want_dgrad: bool = True):
+    """One pass over a float32 checkpoint filter [O, I, kh, kw] / [O, I] -> (fwd [O', kh*kw*I], dgrad [kh*kw*I, O'] with the
+    taps rotated: the filter of the input-gradient pass).  ``fwd`` / ``dgrad`` may be row / column ranges of fused
+    buffers (q|k|v, the time projections): fwd a contiguous row range, dgrad a column range (its row pitch is kept)."""
+    _gpu(w, fwd, dgrad)
+    w = w.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.to(torch.float32).contiguous()
+    if w.dim() == 2:
+        o, i, kh, kw = w.shape[0], w.shape[1], 1, 1
+    else:
+        o, i, kh, kw = w.shape
+    k = kh * kw * i
+    if fwd is None:
+        fwd = torch.empty((o, k), dtype=dtype, device=w.device)
+    if dgrad is None and want_dgrad:
+        dgrad = torch.empty((k, o), dtype=dtype, device=w.device)
+    if fwd.shape != (o, k) or not fwd.is_contiguous() or fwd.dtype != dtype:
+        raise ValueError("pack_weight_pair: fwd must be a contiguous (O, K) row range in the packed dtype")
+    ld = 0
+    if dgrad is not None:
+        if dgrad.shape != (k, o) or dgrad.stride(1) != 1 or dgrad.dtype != dtype:
+            raise ValueError("pack_weight_pair: dgrad must be a (K, O) column range with unit column stride")
+        ld = dgrad.stride(0)
+    with torch.cuda.device(w.device):
+        _lib.check(_lib.load().ldm_pack_weight_pair(w.data_ptr(), fwd.data_ptr(), _ptr(dgrad), dt_code(dtype), o, i, kh, kw,
+                                                    1 if glu_pairs else 0, ld, _stream(w)), "ldm_pack_weight_pair")
+    if dgrad is not None and dgrad.is_contiguous():
+        dgrad = dgrad.view(i, kh * kw * o)          # the K-contiguous filter of the dgrad GEMM: N = Cin, K = taps * Cout
+    return fwd, dgrad
+
+
 def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
               upsample: bool = False, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, silu: bool = False, glu: Optional[str] = None,

@@ -26,6 +26,7 @@ from typing import List, Optional, Union
 
 import torch
 from torch import nn
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import _train, ops
 
@@ -50,18 +51,50 @@ def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
 
 
 # --------------------------------------------------------------------------------------- packed weights
+# Optimizers that update parameters through fused multi-tensor kernels (torch.optim.AdamW(fused=True)) do not bump the
+# parameters' version counters, so the packed-weight cache also keys on a global count of optimizer steps.
+_optimizer_steps = [0]
+
+
+def _count_optimizer_step(*_args, **_kwargs):
+    _optimizer_steps[0] += 1
+
+
+register_optimizer_step_post_hook(_count_optimizer_step)
+
+
+def param_state_key(module: nn.Module):
+    """Changes whenever a parameter of ``module`` may have changed: in-place ops and copies (version counters), moved
+    storage (addresses), any optimizer step.  Writes through ``.data`` / raw pointers that bypass all three need
+    ``invalidate_packed_weights()``."""
+    return (_optimizer_steps[0], tuple((p._version, p.data_ptr()) for p in module.parameters()))
+
+
 def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
     """Derived, K-contiguous copies of every filter under ``root`` in the compute dtype, keyed by module path.
     Checkpoint layout stays PyTorch's ([out, in, kh, kw]); these are rebuilt when a parameter changes.
-    train: also the filters of the input-gradient pass (``.wd``: in/out transposed, taps rotated)."""
+    train: also the filters of the input-gradient pass (``.wd``: in/out transposed, taps rotated), produced by the same
+    pass over the checkpoint tensor (ldm_pack_weight_pair)."""
     P = {}
-
-    def dgrad(key, w):
-        if train:
-            P[key + ".wd"] = ops.pack_weight_dgrad(w, dtype)
 
     def f32(p):
         return p.detach().to(torch.float32).contiguous()
+
+    def pack_fused(key, weights):
+        """Several filters sharing their input, stacked along the output dimension, as one filter."""
+        rows = sum(w.shape[0] for w in weights)
+        k = weights[0][0].numel()
+        dev = weights[0].device
+        fwd = torch.empty((rows, k), dtype=dtype, device=dev)
+        dg = torch.empty((k, rows), dtype=dtype, device=dev) if train else None
+        r = 0
+        for w in weights:
+            n = w.shape[0]
+            ops.pack_weight_pair(w, dtype, fwd=fwd[r:r + n], dgrad=None if dg is None else dg[:, r:r + n], want_dgrad=train)
+            r += n
+        P[key + ".w"] = fwd
+        if train:
+            P[key + ".wd"] = dg
 
     with torch.no_grad():
         for name, mod in root.named_modules():
@@ -72,8 +105,10 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
                 continue
             elif isinstance(mod, (nn.Conv2d, nn.Linear)):
                 glu = name.endswith("w1_w2")
-                P[name + ".w"] = ops.pack_weight(mod.weight, dtype, glu_pairs=glu)
-                dgrad(name, _train.glu_rows_to_packed(mod.weight.detach()) if glu else mod.weight)
+                if train:
+                    P[name + ".w"], P[name + ".wd"] = ops.pack_weight_pair(mod.weight, dtype, glu_pairs=glu)
+                else:
+                    P[name + ".w"] = ops.pack_weight(mod.weight, dtype, glu_pairs=glu)
                 if mod.bias is not None:
                     P[name + ".b"] = ops.pack_weight(mod.bias, torch.float32, glu_pairs=True).flatten() if glu \
                         else f32(mod.bias)
@@ -81,15 +116,11 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
                 P[name + ".g"] = f32(mod.weight)
                 P[name + ".b"] = f32(mod.bias)
             if isinstance(mod, Attention) and mod.fused_qkv:
-                wqkv = torch.cat([mod.q_proj.weight, mod.kv_proj.weight], 0)
-                P[_j(name, "qkv.w")] = ops.pack_weight(wqkv, dtype)
-                dgrad(_j(name, "qkv"), wqkv)
+                pack_fused(_j(name, "qkv"), [mod.q_proj.weight, mod.kv_proj.weight])
         resnets = [(n, m) for n, m in root.named_modules() if isinstance(m, ResnetBlock)]
         if isinstance(root, UNet) and resnets:
             # all time projections (unet.py:703) as one filter; each resnet reads its column slice
-            wt = torch.cat([m.time[1].weight for _, m in resnets], 0)
-            P["time_all.w"] = ops.pack_weight(wt, dtype)
-            dgrad("time_all", wt)
+            pack_fused("time_all", [m.time[1].weight for _, m in resnets])
             P["time_all.b"] = f32(torch.cat([m.time[1].bias for _, m in resnets], 0))
             off = 0
             for n, m in resnets:
@@ -102,7 +133,7 @@ class _HipModule(nn.Module):
     """Caches the packed weights of the tree rooted here until any parameter changes (optimizer step, load)."""
 
     def _packed_for(self, dtype: torch.dtype, train: bool = False) -> dict:
-        ver = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        ver = param_state_key(self)
         cache = self.__dict__.setdefault("_ldm_cache", {})
         if cache.get("ver") != ver:
             cache.clear()
@@ -113,6 +144,10 @@ class _HipModule(nn.Module):
                 cache.pop((dtype, False))      # the training set contains the inference set
             cache[key] = pack_tree(self, dtype, train)
         return cache[key]
+
+    def invalidate_packed_weights(self):
+        """Drop the derived filters (after writing parameters in a way torch cannot see)."""
+        self.__dict__.pop("_ldm_cache", None)
 
     def _check_call(self, x: torch.Tensor, *others) -> bool:
         """Validates the call; True when autograd is recording and the training form must run."""

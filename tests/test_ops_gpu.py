@@ -550,3 +550,26 @@ def test_conv_in_out(dtype, B, H, W, C):
     z = ops.conv_out(hd, w2.cuda(), b2.cuda(), dtype)
     assert z.shape == (B, 4, H, W)
     assert rel_l2(z, F.conv2d(hr.permute(0, 3, 1, 2), w2, b2, padding=1)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,glu", [((64, 96, 3, 3), False), ((40, 24, 3, 3), False), ((320, 768), False), ((128, 40), True),
+                                       ((33, 7, 3, 3), False)])
+def test_pack_weight_pair_matches_the_two_single_packs(dtype, shape, glu):
+    """ldm_pack_weight_pair (one pass, both layouts) against ldm_pack_weight of the filter and of its transposed / rotated
+    form, bit for bit; ragged extents; column ranges of a fused dgrad buffer."""
+    ops = _ops()
+    from ldm._train import glu_rows_to_packed
+    w = seeded(shape, 5).cuda()
+    fwd, dg = ops.pack_weight_pair(w, dtype, glu_pairs=glu)
+    assert torch.equal(fwd, ops.pack_weight(w, dtype, glu_pairs=glu))
+    assert torch.equal(dg, ops.pack_weight_dgrad(glu_rows_to_packed(w) if glu else w, dtype))
+    if len(shape) == 2 and not glu:
+        w2 = seeded((shape[0] + 32, shape[1]), 6).cuda()
+        rows = shape[0] + w2.shape[0]
+        f = torch.zeros(rows, shape[1], dtype=dtype, device="cuda")
+        d = torch.zeros(shape[1], rows, dtype=dtype, device="cuda")
+        ops.pack_weight_pair(w, dtype, fwd=f[:shape[0]], dgrad=d[:, :shape[0]])
+        ops.pack_weight_pair(w2, dtype, fwd=f[shape[0]:], dgrad=d[:, shape[0]:])
+        cat = torch.cat([w, w2], 0)
+        assert torch.equal(f, ops.pack_weight(cat, dtype)) and torch.equal(d, ops.pack_weight_dgrad(cat, dtype))

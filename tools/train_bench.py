@@ -7,8 +7,8 @@ bucketed gradient all-reduce of ldm/parallel.py overlapped when launched on N GP
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         tools/train_bench.py --batch 32 --steps 5
 
-The loss, the clip and the optimizer are torch's (the caller's side of the path); UNet forward/backward and
-add_noise are the HIP kernels.  Prints one JSON line: img/s over all ranks, ms per phase (HIP events on rank 0), the
+UNet forward/backward and add_noise are the HIP kernels; the loss, the clip and the optimizer are the fused HIP tail of
+ldm/optim.py or, with --torch-tail, the torch ops the reference's trainer calls.  Prints one JSON line: img/s over all ranks, ms per phase (HIP events on rank 0), the
 fraction of the dense bf16 MFMA peak at 3x forward FLOPs per image, and the peak device memory."""
 from __future__ import annotations
 
@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--bucket-mb", type=float, default=64.0)
     ap.add_argument("--small", action="store_true", help="config-1 network (plumbing check)")
+    ap.add_argument("--torch-tail", action="store_true", help="loss / clip / AdamW with torch ops (the reference's own) instead "
+                    "of the fused HIP tail (ldm/optim.py)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -58,7 +60,11 @@ def main():
     init_weights_(net, seed=1234)
     net.train()
     model = DataParallel(net, bucket_mb=args.bucket_mb)
-    opt = torch.optim.AdamW(net.parameters(), lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, fused=True)
+    from ldm.optim import FusedAdamW, mse_loss
+    if args.torch_tail:
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, fused=True)
+    else:
+        opt = FusedAdamW(net.parameters(), lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
     sched = DDPMScheduler(device=dev)
 
     B, L = args.batch, 64
@@ -76,13 +82,20 @@ def main():
         noisy = sched.add_noise(lat, noise, t)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             pred = model(noisy, t, ctx)
-        loss = F.mse_loss(pred.float(), noise.float(), reduction="mean")
-        if rec:
-            rec[1].record()
-        loss.backward()
+        if args.torch_tail:
+            loss = F.mse_loss(pred.float(), noise.float(), reduction="mean")
+            if rec:
+                rec[1].record()
+            loss.backward()
+        else:
+            loss, dpred = mse_loss(pred.detach(), noise)      # loss and its gradient in one pass
+            if rec:
+                rec[1].record()
+            pred.backward(dpred)
         if rec:
             rec[2].record()
-        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        if args.torch_tail:
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
         if rec:
             rec[3].record()
         opt.step()
@@ -120,6 +133,7 @@ def main():
             "phases_ms": {"add_noise+forward+loss": round(ph[0], 2), "backward(+all-reduce)": round(ph[1], 2),
                           "clip_grad_norm": round(ph[2], 2), "adamw+zero_grad": round(ph[3], 2)},
             "frac_of_mfma_peak_at_3x_forward_flops": None if args.small else round(flops / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
+            "tail": "torch" if args.torch_tail else "fused (ldm/optim.py: clip folded into AdamW)",
             "collectives_per_backward": model.reducer.launched, "bucket_mb": args.bucket_mb,
             "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
             "loss": round(float(loss), 5)}), flush=True)
