@@ -41,7 +41,8 @@ class GraphedUNet:
         self._capture()
 
     def _param_versions(self):
-        return tuple((q._version, q.data_ptr()) for q in self.net.parameters())
+        from .unet import param_state_key
+        return param_state_key(self.net)
 
     def _forward(self):
         if self.compute_dtype == torch.bfloat16 and self.sample.dtype != torch.bfloat16:
