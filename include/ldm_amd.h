@@ -85,6 +85,23 @@ int ldm_ddpm_add_noise(const void* x0, const void* noise, float* out, int dtype,
                        const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
                        int T, int batch, int64_t per_sample, void* stream);
 
+/* Training-side input preparation in one pass (train_latent_diffusion.py:1039-1064), float32:
+ *   latents = scaling * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps)   moments = (mean | logvar): [batch][2*channels][hw]
+ *                                                                           (vae._encode output, :1036; diffusers
+ *                                                                           DiagonalGaussianDistribution.sample, :1039-1040)
+ *   noise  += noise_offset * offset[b][c]        if offset != NULL (:1043-1048; written back: it is the loss target)
+ *   noisy   = sqrt_acp[t_b]*latents + sqrt(1-acp)[t_b]*(noise + perturbation*extra)   (extra may be NULL; :1049-1064)
+ * eps, noise, extra, latents, noisy: [batch][channels][hw]; all random draws are the caller's.  t, sa, so as ldm_ddpm_add_noise. */
+int ldm_train_input_prep(const float* moments, const float* eps, float* noise, const float* offset, const float* extra,
+                         const int64_t* t, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod, int T,
+                         int batch, int channels, int64_t hw, float scaling, float noise_offset, float perturbation,
+                         float* latents, float* noisy, void* stream);
+
+/* enc[b] = drop[b] ? null_emb : enc[b], in place: text-conditioning dropout (:1073-1079).  enc [batch][per_sample], null_emb
+ * [per_sample] in dtype; drop: DEVICE bytes. */
+int ldm_cond_dropout(void* enc, const void* null_emb, const unsigned char* drop, int dtype, int batch, int64_t per_sample,
+                     void* stream);
+
 /* ------------------------------------------------------------------------- UNet: weight packing */
 
 /* dst[o'][kh][kw][ci] = src[o][ci][kh][kw] (src float32 OIHW / [out,in]; dst dtype LDM_BF16 or LDM_F32).

@@ -235,6 +235,55 @@ ddpm_add_noise_kernel(const T* __restrict__ x0, const T* __restrict__ noise, flo
   }
 }
 
+// Training-side input preparation in one pass (train_latent_diffusion.py:1039-1064): posterior sample of the
+// VAE's (mean | logvar) moments times the scaling factor, optional offset noise (one draw per sample and channel), optional
+// input perturbation, then q(x_t | x_0).  All draws are inputs (the caller's torch generators).  float32 throughout, every
+// product and sum rounded separately (-ffp-contract=off) like the torch ops it replaces.
+//   latents = sf * (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps)          diffusers DiagonalGaussianDistribution.sample
+//   noise'  = noise + noise_offset * offset[b][c]                             (:1046)
+//   noisy   = sqrt_acp[t_b] * latents + sqrt(1 - acp)[t_b] * (noise' + perturbation * extra)     (:1050, :1062)
+__global__ void __launch_bounds__(256)
+train_input_prep_kernel(const float* __restrict__ moments, const float* __restrict__ eps, float* __restrict__ noise,
+                        const float* __restrict__ offset, const float* __restrict__ extra, const int64_t* __restrict__ t,
+                        const float* __restrict__ sa, const float* __restrict__ so, int T_steps, int channels, int64_t hw,
+                        float scaling, float noise_offset, float perturbation, float* __restrict__ latents,
+                        float* __restrict__ noisy) {
+  const int b = blockIdx.y;
+  int64_t tb = t[b];
+  tb = tb < 0 ? 0 : (tb >= T_steps ? T_steps - 1 : tb);
+  const float a = sa[tb], s = so[tb];
+  const int64_t per_sample = (int64_t)channels * hw;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+    const int c = (int)(i / hw);
+    const int64_t o = (int64_t)b * per_sample + i;
+    const float mean = moments[(int64_t)b * 2 * per_sample + i];
+    float logvar = moments[(int64_t)b * 2 * per_sample + per_sample + i];
+    logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
+    const float std_ = expf(0.5f * logvar);
+    const float lat = scaling * (mean + std_ * eps[o]);
+    float nz = noise[o];
+    if (offset != nullptr) {
+      nz = nz + noise_offset * offset[b * channels + c];
+      noise[o] = nz;                                   // the loss target is the offset noise (:1108 uses `noise`)
+    }
+    const float nin = extra != nullptr ? nz + perturbation * extra[o] : nz;
+    latents[o] = lat;
+    noisy[o] = a * lat + s * nin;
+  }
+}
+
+// enc_h[b] = drop[b] ? null_emb : enc_h[b]   (text-conditioning dropout, :1076-1079), in place; T = bf16 or float
+template <typename T>
+__global__ void __launch_bounds__(256)
+cond_dropout_kernel(T* __restrict__ enc, const T* __restrict__ null_emb, const unsigned char* __restrict__ drop, int64_t per_sample) {
+  const int b = blockIdx.y;
+  if (!drop[b]) return;
+  T* e = enc + (int64_t)b * per_sample;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) e[i] = null_emb[i];
+}
+
 static int grid_for(int64_t work_items, int block) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
@@ -309,5 +358,40 @@ extern "C" int ldm_ddpm_add_noise(const void* x0, const void* noise, float* out,
     hipLaunchKernelGGL((ddpm_add_noise_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x0, (const bf16_t*)noise,
                        (float*)out, t, sa, so, T, per_sample, vec_ok);
   LDM_HIP_CHECK_LAUNCH("ldm_ddpm_add_noise");
+  return LDM_OK;
+}
+
+extern "C" int ldm_train_input_prep(const float* moments, const float* eps, float* noise, const float* offset, const float* extra,
+                                    const int64_t* t, const float* sa, const float* so, int T, int batch, int channels, int64_t hw,
+                                    float scaling, float noise_offset, float perturbation, float* latents, float* noisy,
+                                    void* stream) {
+  LDM_REQUIRE(batch >= 0 && channels >= 1 && hw >= 1 && T >= 1, "ldm_train_input_prep: bad sizes");
+  if (batch == 0) return LDM_OK;
+  LDM_REQUIRE(batch <= 65535, "ldm_train_input_prep: batch %d exceeds 65535", batch);
+  LDM_REQUIRE(moments && eps && noise && t && sa && so && latents && noisy, "ldm_train_input_prep: null pointer");
+  int gx = grid_for((int64_t)channels * hw, 256);
+  if ((int64_t)gx * batch > 4096) gx = (int)((4096 + batch - 1) / batch);
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(train_input_prep_kernel, dim3(gx, batch), dim3(256), 0, (hipStream_t)stream, moments, eps, noise, offset, extra, t,
+                     sa, so, T, channels, hw, scaling, noise_offset, perturbation, latents, noisy);
+  LDM_HIP_CHECK_LAUNCH("ldm_train_input_prep");
+  return LDM_OK;
+}
+
+extern "C" int ldm_cond_dropout(void* enc, const void* null_emb, const unsigned char* drop, int dtype, int batch, int64_t per_sample,
+                                void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_cond_dropout: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && per_sample >= 0, "ldm_cond_dropout: bad sizes");
+  if (batch == 0 || per_sample == 0) return LDM_OK;
+  LDM_REQUIRE(batch <= 65535, "ldm_cond_dropout: batch %d exceeds 65535", batch);
+  LDM_REQUIRE(enc && null_emb && drop, "ldm_cond_dropout: null pointer");
+  int gx = grid_for(per_sample, 256);
+  if (gx > 64) gx = 64;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((cond_dropout_kernel<bf16_t>), dim3(gx, batch), dim3(256), 0, st, (bf16_t*)enc, (const bf16_t*)null_emb, drop, per_sample);
+  else
+    hipLaunchKernelGGL((cond_dropout_kernel<float>), dim3(gx, batch), dim3(256), 0, st, (float*)enc, (const float*)null_emb, drop, per_sample);
+  LDM_HIP_CHECK_LAUNCH("ldm_cond_dropout");
   return LDM_OK;
 }

@@ -148,3 +148,38 @@ def test_add_noise(golden, sched):
         assert outb.dtype == refb.dtype == torch.float32 and same_bits(outb, refb), shape
     with pytest.raises(ValueError):
         sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), torch.zeros(3, dtype=torch.long, device="cuda"))
+
+
+def test_fused_training_input_prep_matches_the_reference_sequence():
+    """ldm/train_inputs.py against the torch op sequence of train_latent_diffusion.py:1039-1079 with the same
+    generator: posterior sample x scaling, offset noise, input perturbation, add_noise (oracle), conditioning dropout."""
+    import torch
+    from ldm import train_inputs
+    from ldm.scheduling_ddpm import DDPMScheduler
+    from oracle import scheduler_ref as sref
+    dev = torch.device("cuda")
+    sch = DDPMScheduler(device=dev)
+    moments = torch.randn(5, 8, 16, 12, generator=torch.Generator().manual_seed(3)).cuda()
+    moments[:, 4:] = moments[:, 4:] * 20      # logvar beyond the clamp on both sides
+    for off, pert in ((0.0, 0.0), (0.1, 0.0), (0.05, 0.2)):
+        got = train_inputs.prepare_inputs(sch, moments, 0.18215, noise_offset=off, input_perturbation=pert,
+                                          generator=torch.Generator(device=dev).manual_seed(9))
+        g = torch.Generator(device=dev).manual_seed(9)
+        mean, logvar = moments.float().chunk(2, dim=1)
+        std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+        lat = 0.18215 * (mean + std * torch.randn(mean.shape, device=dev, generator=g))
+        noise = torch.randn(lat.shape, device=dev, generator=g)
+        if off:
+            noise = noise + off * torch.randn((5, 4, 1, 1), device=dev, generator=g)
+        nin = noise + pert * torch.randn(lat.shape, device=dev, generator=g) if pert else noise
+        t = torch.randint(0, 1000, (5,), dtype=torch.int64, device=dev, generator=g)
+        noisy = sref.add_noise(sref.build_tables(), lat.cpu(), nin.cpu(), t.cpu())
+        assert torch.equal(got.timesteps, t)
+        assert rel_l2(got.latents, lat) < 1e-6 and rel_l2(got.noise, noise) < 1e-7
+        assert rel_l2(got.noisy_latents, noisy) < 1e-6
+    enc = torch.randn(6, 77, 768, device=dev).bfloat16()
+    null = torch.randn(1, 77, 768, device=dev).bfloat16()
+    mask = torch.tensor([0, 1, 0, 0, 1, 1], dtype=torch.bool, device=dev)
+    ref = enc.clone()
+    ref[mask] = null
+    assert torch.equal(train_inputs.drop_conditioning(enc, null, mask), ref)
