@@ -94,6 +94,7 @@ colsum_fold_kernel(const float* __restrict__ partial, int nslabs, int n, long lo
   const long long seg = idx / n;
   const int col = (int)(idx - seg * n);
   float v = accumulate ? out[idx] : 0.f;
+#pragma unroll 8
   for (int s = 0; s < nslabs; ++s) v += partial[(seg * nslabs + s) * n + col];
   out[idx] = v;
 }
@@ -260,32 +261,47 @@ gn_bwd_partial_kernel(const T* __restrict__ a0, const T* __restrict__ a1, const 
   }
 }
 
-// One workgroup per sample: fold the slabs per channel (-> ab[b][c][2]), then the group sums (-> gsum[b][g][2]).
+// One workgroup per (sample, range of groups): fold the slabs per channel (-> ab[b][c][2]), then the group sums
+// (-> gsum[b][g][2]).  gridDim.y ranges of whole groups keep 4x more workgroups busy than one per sample; four slabs are
+// in flight per thread.  Fixed summation order.
 __global__ void __launch_bounds__(256)
 gn_bwd_fold_kernel(const float* __restrict__ partial, int nslabs, int ctot, int groups, const float* __restrict__ gamma,
                    float* __restrict__ ab, float* __restrict__ gsum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* ga = reinterpret_cast<float*>(smem_raw);    // [ctot][2] : gamma * A, gamma * B
+  float* ga = reinterpret_cast<float*>(smem_raw);    // [channels of this range][2] : gamma * A, gamma * B
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < ctot; c += 256) {
+  const int cpg = ctot / groups;
+  const int gper = groups / gridDim.y;               // whole groups per workgroup (host: groups % gridDim.y == 0)
+  const int g0 = blockIdx.y * gper;
+  const int c_begin = g0 * cpg, c_end = (g0 + gper) * cpg;
+  const float2* part2 = reinterpret_cast<const float2*>(partial);
+  for (int c = c_begin + threadIdx.x; c < c_end; c += 256) {
     float a = 0.f, q = 0.f;
-    for (int s = 0; s < nslabs; ++s) {
-      const float* o = partial + (((size_t)b * nslabs + s) * ctot + c) * 2;
-      a += o[0];
-      q += o[1];
+    int s = 0;
+    for (; s + 3 < nslabs; s += 4) {
+      const float2 v0 = part2[((size_t)b * nslabs + s) * ctot + c];
+      const float2 v1 = part2[((size_t)b * nslabs + s + 1) * ctot + c];
+      const float2 v2 = part2[((size_t)b * nslabs + s + 2) * ctot + c];
+      const float2 v3 = part2[((size_t)b * nslabs + s + 3) * ctot + c];
+      a = (((a + v0.x) + v1.x) + v2.x) + v3.x;
+      q = (((q + v0.y) + v1.y) + v2.y) + v3.y;
+    }
+    for (; s < nslabs; ++s) {
+      const float2 v = part2[((size_t)b * nslabs + s) * ctot + c];
+      a += v.x;
+      q += v.y;
     }
     ab[((size_t)b * ctot + c) * 2] = a;
     ab[((size_t)b * ctot + c) * 2 + 1] = q;
-    ga[2 * c] = gamma[c] * a;
-    ga[2 * c + 1] = gamma[c] * q;
+    ga[2 * (c - c_begin)] = gamma[c] * a;
+    ga[2 * (c - c_begin) + 1] = gamma[c] * q;
   }
   __syncthreads();
-  const int cpg = ctot / groups;
-  for (int g = threadIdx.x; g < groups; g += 256) {
+  for (int g = threadIdx.x; g < gper; g += 256) {
     float s1 = 0.f, s2 = 0.f;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s1 += ga[2 * c]; s2 += ga[2 * c + 1]; }
-    gsum[((size_t)b * groups + g) * 2] = s1;
-    gsum[((size_t)b * groups + g) * 2 + 1] = s2;
+    gsum[((size_t)b * groups + g0 + g) * 2] = s1;
+    gsum[((size_t)b * groups + g0 + g) * 2 + 1] = s2;
   }
 }
 
@@ -441,23 +457,40 @@ ln_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, long long rows,
   }
 }
 
-// dgamma[c] (+)= sum_w colpart[w][c][0], dbeta[c] (+)= sum_w colpart[w][c][1]; one wave per column, fixed butterfly
+// dgamma[c] (+)= sum_w colpart[w][c][0], dbeta[c] (+)= sum_w colpart[w][c][1].  Workgroup = 16 columns x 16 row-lanes:
+// every load instruction covers whole 128-byte lines of colpart, four rows in flight per thread; fixed summation order.
 __global__ void __launch_bounds__(256)
 ln_bwd_param_kernel(const float* __restrict__ colpart, long long nwaves, int cols, int accumulate, float* __restrict__ dgamma,
                     float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= cols) return;
+  __shared__ float2 red[16][17];
+  const int cl = threadIdx.x & 15, wl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  const float2* part2 = reinterpret_cast<const float2*>(colpart);
   float a = 0.f, q = 0.f;
-  for (long long w = lane; w < nwaves; w += 64) {
-    a += colpart[((size_t)w * cols + c) * 2];
-    q += colpart[((size_t)w * cols + c) * 2 + 1];
+  if (c < cols) {
+    long long w = wl;
+    for (; w + 48 < nwaves; w += 64) {
+      const float2 v0 = part2[(size_t)w * cols + c];
+      const float2 v1 = part2[(size_t)(w + 16) * cols + c];
+      const float2 v2 = part2[(size_t)(w + 32) * cols + c];
+      const float2 v3 = part2[(size_t)(w + 48) * cols + c];
+      a = (((a + v0.x) + v1.x) + v2.x) + v3.x;
+      q = (((q + v0.y) + v1.y) + v2.y) + v3.y;
+    }
+    for (; w < nwaves; w += 16) {
+      const float2 v = part2[(size_t)w * cols + c];
+      a += v.x;
+      q += v.y;
+    }
   }
-  a = wave_sum(a);
-  q = wave_sum(q);
-  if (lane == 0) {
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + a;
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + q;
+  red[wl][cl] = make_float2(a, q);
+  __syncthreads();
+  if (wl == 0 && c < cols) {
+    float sa = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { sa += red[k][cl].x; sq += red[k][cl].y; }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + sa;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + sq;
   }
 }
 
@@ -636,8 +669,9 @@ extern "C" int ldm_groupnorm_backward(const void* a0, const void* a1, int c0, in
     hipLaunchKernelGGL((gn_bwd_partial_kernel<float>), grid, dim3(GB_THREADS), smem, st, (const float*)a0, (const float*)a1,
                        (const float*)dy, g, stats, gamma, beta, silu, partial);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_backward(partial)");
-  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(batch), dim3(256), (size_t)g.ctot * 2 * sizeof(float), st, partial, nslabs, g.ctot, groups,
-                     gamma, ab, gsum);
+  const int gsplit = groups % 4 == 0 ? 4 : 1;
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(batch, gsplit), dim3(256), (size_t)(g.ctot / gsplit) * 2 * sizeof(float), st, partial,
+                     nslabs, g.ctot, groups, gamma, ab, gsum);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_backward(fold)");
   hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((g.ctot + 255) / 256), dim3(256), 0, st, ab, batch, g.ctot, accumulate, dgamma, dbeta);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_backward(param)");
@@ -673,7 +707,7 @@ extern "C" int ldm_layernorm_backward(const void* x, const void* dy, int dtype, 
   }
 #undef LDM_LNB
   LDM_HIP_CHECK_LAUNCH("ldm_layernorm_backward");
-  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((cols + 3) / 4), dim3(256), 0, st, workspace, blocks * 4, cols, accumulate, dgamma, dbeta);
+  hipLaunchKernelGGL(ln_bwd_param_kernel, dim3((cols + 15) / 16), dim3(256), 0, st, workspace, blocks * 4, cols, accumulate, dgamma, dbeta);
   LDM_HIP_CHECK_LAUNCH("ldm_layernorm_backward(param)");
   return LDM_OK;
 }
