@@ -321,6 +321,26 @@ int ldm_conv_in(const void* x, int x_dtype, const float* w, const float* bias, v
 int ldm_conv_out(const void* x, int x_dtype, const float* w, const float* bias, void* out, int out_dtype,
                  int batch, int cin, int h, int wd, int cout, void* stream);
 
+/* ---- VAE-decoder leg of `generate` (train_latent_diffusion.py:596-601).  The decoder itself is diffusers'
+ * AutoencoderKL.decode (third-party, version unpinned in the reference's pyproject.toml:28, absent offline; layer stack in the
+ * reference's VAE.md:119-157): everything but the three entry points below is the UNet's GroupNorm / conv-GEMM kernels. */
+
+/* out[r][c] = softmax over c < valid_cols of scale * scores[r][c], zero for valid_cols <= c < cols.  The decoder's
+ * mid-block attention (VAE.md:132-137) is one head of 512 channels: its scores are materialised by ldm_conv_gemm (float32
+ * out), normalised here, and multiplied with V by a second ldm_conv_gemm.  scores float32 [rows][ld_in]; out in out_dtype
+ * [rows][ld_out]; scale > 0. */
+int ldm_softmax_rows(const float* scores, long long ld_in, long long rows, int cols, int valid_cols, float scale, void* out,
+                     int out_dtype, long long ld_out, void* stream);
+
+/* post_quant_conv (VAE.md:125): 1x1 conv over an NCHW tensor of at most 8 channels, float32 NCHW out.
+ * x: [batch][cin][hw] in x_dtype; w: float32 [cout][cin]; bias float32 [cout]. */
+int ldm_conv1x1_nchw(const void* x, int x_dtype, const float* w, const float* bias, float* out, int batch, int cin, int cout,
+                     long long hw, void* stream);
+
+/* train_latent_diffusion.py:600-601: out = uint8(255 * clamp(x / 2 + 0.5, 0, 1)), each intermediate rounded to dtype as
+ * torch rounds it, the final cast truncating. */
+int ldm_image_to_uint8(const void* x, int dtype, unsigned char* out, long long n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

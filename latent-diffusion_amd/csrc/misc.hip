@@ -91,16 +91,18 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, int batch
 template <typename TX, typename TO, int CIN>
 __global__ void __launch_bounds__(256)
 conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
-               int batch, int h, int wd, int cout) {
+               int batch, int h, int wd, int cout, int cblk) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* wl = reinterpret_cast<float*>(smem_raw);  // [CIN*9][cout]
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [CIN*9][cb]: this workgroup's range of output channels (blockIdx.y)
   constexpr int TAPS = CIN * 9;
-  for (int i = threadIdx.x; i < TAPS * cout; i += 256) {
+  const int co0 = blockIdx.y * cblk;
+  const int cb = cout - co0 < cblk ? cout - co0 : cblk;
+  for (int i = threadIdx.x; i < TAPS * cb; i += 256) {
     const int co = i / TAPS, tap = i - co * TAPS;   // w is [cout][CIN][3][3]
-    wl[tap * cout + co] = w[i];
+    wl[tap * cb + co] = w[(size_t)co0 * TAPS + i];
   }
   __syncthreads();
-  const int chunks = cout >> 3;
+  const int chunks = cb >> 3;
   const int64_t total = (int64_t)batch * h * wd * chunks;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -110,7 +112,7 @@ conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const floa
     const int oh = (int)((pix / wd) % h);
     const int b = (int)(pix / ((int64_t)wd * h));
     float acc[8];
-    load8(bias + ch * 8, acc);
+    load8(bias + co0 + ch * 8, acc);
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
 #pragma unroll
@@ -122,13 +124,13 @@ conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const floa
           float v = 0.f;
           if (ih >= 0 && ih < h && iw >= 0 && iw < wd) v = Elem<TX>::ld(x + (((int64_t)b * CIN + ci) * h + ih) * wd + iw);
           float wv[8];
-          load8(wl + ((ci * 3 + kh) * 3 + kw) * cout + ch * 8, wv);
+          load8(wl + ((ci * 3 + kh) * 3 + kw) * cb + ch * 8, wv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] += v * wv[j];
         }
       }
     }
-    store8(out + pix * cout + ch * 8, acc);
+    store8(out + pix * cout + co0 + ch * 8, acc);
   }
 }
 
@@ -195,6 +197,68 @@ conv_out_kernel(const TX* __restrict__ x, const float* __restrict__ w, const flo
   }
 #pragma unroll
   for (int co = 0; co < COUT; ++co) Elem<TO>::st(out + (((int64_t)b * COUT + co) * h + oh) * wd + ow, acc[co]);
+}
+
+// Wide-image form of the final conv (the VAE decoder's 128 -> 3 at up to 768x768): 16 lanes per output pixel, each lane
+// owning 8-channel chunks of the pixel's NHWC row, so a wave reads 4 neighbouring pixels as one contiguous run per tap; the
+// filter sits in LDS as [tap][cin][COUT] (lanes of a pixel read neighbouring words, the four pixels broadcast); partial
+// sums meet in a 16-lane butterfly.  Summation order is fixed.
+template <typename TX, typename TO, int COUT>
+__global__ void __launch_bounds__(256)
+conv_out_lanes_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
+                      int batch, int cin, int h, int wd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [9][cin][COUT]
+  for (int i = threadIdx.x; i < 9 * cin * COUT; i += 256) {
+    const int co = i % COUT, c = (i / COUT) % cin, tap = i / (COUT * cin);
+    wl[i] = w[((size_t)co * cin + c) * 9 + tap];   // w is [COUT][cin][3][3]
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const int chunks = cin >> 3;
+  const int64_t npix = (int64_t)batch * h * wd;
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  for (int64_t pix = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix - (threadIdx.x >> 4) < npix; pix += stride) {
+    const bool live = pix < npix;                  // whole 16-lane groups stay in the loop for the butterfly
+    const int ow = (int)(pix % wd);
+    const int oh = (int)((pix / wd) % h);
+    const int64_t b = pix / ((int64_t)wd * h);
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    if (live) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
+        if (ih < 0 || ih >= h) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow + kw - 1;
+          if (iw < 0 || iw >= wd) continue;
+          const TX* row = x + ((b * h + ih) * wd + iw) * cin;
+          const float* wt = wl + (size_t)(kh * 3 + kw) * cin * COUT;
+          for (int ch = sub; ch < chunks; ch += 16) {
+            float v[8];
+            load8(row + ch * 8, v);
+            const float* wp = wt + ch * 8 * COUT;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+              for (int co = 0; co < COUT; ++co) acc[co] += v[j] * wp[j * COUT + co];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc[co] += __shfl_xor(acc[co], o, 16);
+    }
+    if (live && sub < COUT) {
+      float r = acc[0];
+#pragma unroll
+      for (int co = 1; co < COUT; ++co) r = sub == co ? acc[co] : r;
+      Elem<TO>::st(out + ((b * COUT + sub) * h + oh) * wd + ow, r + bias[sub]);
+    }
+  }
 }
 
 template <typename T>
@@ -267,11 +331,13 @@ template <typename TX, typename TO>
 static int conv_in_dispatch(const void* x, const float* w, const float* bias, void* out, int batch, int cin, int h,
                             int wd, int cout, hipStream_t st) {
   const int64_t npix = (int64_t)batch * h * wd;
-  if (cin == 4 && cout % 8 == 0 && cout <= 448 && aligned16(out) && aligned16(bias)) {
-    int64_t nb = (npix * (cout / 8) + 255) / 256;
+  if (cin == 4 && cout % 8 == 0 && aligned16(out) && aligned16(bias)) {
+    const int cblk = cout <= 448 ? cout : 256;   // output channels per workgroup: 36 * cblk floats of LDS (<= 64 KB)
+    const int ny = (cout + cblk - 1) / cblk;
+    int64_t nb = (npix * (cblk / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;  // grid-stride: the LDS filter image is filled once per block
-    hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3((int)nb), dim3(256), (size_t)36 * cout * sizeof(float), st, (const TX*)x,
-                       w, bias, (TO*)out, batch, h, wd, cout);
+    hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3((int)nb, ny), dim3(256), (size_t)36 * cblk * sizeof(float), st, (const TX*)x,
+                       w, bias, (TO*)out, batch, h, wd, cout, cblk);
   } else {
     hipLaunchKernelGGL((conv_in_generic_kernel<TX, TO>), dim3(blocks_for(npix * cout)), dim3(256), 0, st, (const TX*)x, w, bias,
                        (TO*)out, batch, cin, h, wd, cout);
@@ -299,6 +365,23 @@ static int conv_out_dispatch(const void* x, const float* w, const float* bias, v
                              int wd, int cout, hipStream_t st) {
   const int64_t npix = (int64_t)batch * h * wd;
   dim3 grid(blocks_for(npix)), block(256);
+  const size_t lds = (size_t)9 * cin * cout * sizeof(float);
+  if (npix >= 65536 && lds <= 65536 && cout <= 4) {   // large images: 16 lanes per pixel, filter in LDS
+    int64_t nb = (npix + 15) / 16;
+    if (nb > 8192) nb = 8192;                        // grid-stride: the LDS filter image is filled once per workgroup
+    const dim3 g((unsigned)nb);
+#define LDM_CONV_OUT_LANES(CO) \
+  hipLaunchKernelGGL((conv_out_lanes_kernel<TX, TO, CO>), g, block, lds, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd)
+    switch (cout) {
+      case 1: LDM_CONV_OUT_LANES(1); break;
+      case 2: LDM_CONV_OUT_LANES(2); break;
+      case 3: LDM_CONV_OUT_LANES(3); break;
+      default: LDM_CONV_OUT_LANES(4); break;
+    }
+#undef LDM_CONV_OUT_LANES
+    LDM_HIP_CHECK_LAUNCH("ldm_conv_out");
+    return LDM_OK;
+  }
 #define LDM_CONV_OUT(CO) \
   hipLaunchKernelGGL((conv_out_kernel<TX, TO, CO>), grid, block, 0, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd)
   switch (cout) {

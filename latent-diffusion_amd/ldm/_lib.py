@@ -101,6 +101,9 @@ _SIGNATURES = {
                     c_void_p],
     "ldm_conv_out": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                      c_void_p],
+    "ldm_softmax_rows": [c_void_p, C.c_longlong, C.c_longlong, c_int, c_int, c_float, c_void_p, c_int, C.c_longlong, c_void_p],
+    "ldm_conv1x1_nchw": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, C.c_longlong, c_void_p],
+    "ldm_image_to_uint8": [c_void_p, c_int, c_void_p, C.c_longlong, c_void_p],
 }
 
 # host-only size queries returning long long

@@ -596,3 +596,43 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_silu(x.data_ptr(), out.data_ptr(), dt_code(x.dtype), x.numel(), _stream(x)), "ldm_silu")
     return out
+
+
+# ----------------------------------------------------------------------------- VAE-decoder leg
+def softmax_rows(scores: torch.Tensor, valid_cols: int, scale: float, out_dtype: torch.dtype) -> torch.Tensor:
+    """scores: float32 (rows, cols).  softmax(scale * scores) over the first valid_cols columns, zeros after."""
+    _gpu(scores)
+    if scores.dim() != 2 or scores.dtype != torch.float32 or scores.stride(1) != 1:
+        raise ValueError("softmax_rows: float32 (rows, cols) with unit column stride expected")
+    rows, cols = scores.shape
+    out = torch.empty((rows, cols), dtype=out_dtype, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(_lib.load().ldm_softmax_rows(scores.data_ptr(), scores.stride(0), rows, cols, valid_cols, scale,
+                                                out.data_ptr(), dt_code(out_dtype), cols, _stream(scores)), "ldm_softmax_rows")
+    return out
+
+
+def conv1x1_nchw(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x: NCHW with at most 8 channels; w: float32 (cout, cin[, 1, 1]); returns float32 NCHW."""
+    _gpu(x, w, bias)
+    x = x.contiguous()
+    B, cin, H, W = x.shape
+    cout = w.shape[0]
+    if w.numel() != cout * cin:
+        raise ValueError("conv1x1_nchw: filter does not match the input channels")
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_conv1x1_nchw(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                B, cin, cout, H * W, _stream(x)), "ldm_conv1x1_nchw")
+    return out
+
+
+def image_to_uint8(x: torch.Tensor) -> torch.Tensor:
+    """(255 * (x / 2 + 0.5).clamp(0, 1)).to(uint8) as one kernel (train_latent_diffusion.py:600-601)."""
+    _gpu(x)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().ldm_image_to_uint8(x.data_ptr(), dt_code(x.dtype), out.data_ptr(), x.numel(), _stream(x)),
+                   "ldm_image_to_uint8")
+    return out
