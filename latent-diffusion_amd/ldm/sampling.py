@@ -1,8 +1,9 @@
 """Latent sampling loop around the hot path, sharded over GPUs by latent.
 
 Counterpart of the reverse-diffusion loop of ``generate`` (ldm/tools/train_latent_diffusion.py:563-593) without the
-tokenizer / text encoder / VAE around it (out of scope: SURVEY.md section 8): ``set_timesteps`` -> for every timestep
-one denoiser forward (two batched forwards' worth with classifier-free guidance, :581-592) -> ``scheduler.step``.
+tokenizer / text encoder around it (out of scope: SURVEY.md section 8): ``set_timesteps`` -> for every timestep one
+denoiser forward (two batched forwards' worth with classifier-free guidance, :581-592) -> ``scheduler.step``; then
+(``decode_images``, :596-601) the VAE decoder of ldm/vae.py and the uint8 conversion.
 
 Multi-GPU: every latent is independent through all steps, so rank g of G owns the contiguous slice
 ``shard_range(N, g, G)`` of the batch and the loop contains NO collective.  So that the result does not depend on G,
@@ -89,6 +90,29 @@ def _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_s
             eps_u, eps_c = denoiser(latent_in, t, both_ctx).chunk(2)
             latents = scheduler.step(eps_u, t, latents, noise=noise, guidance=(eps_c, guidance_scale)).prev_sample
     return latents
+
+
+@torch.inference_mode()
+def decode_images(vae, latents: torch.Tensor, *, compute_dtype: Optional[torch.dtype] = torch.bfloat16,
+                  micro_batch: Optional[int] = None) -> torch.Tensor:
+    """train_latent_diffusion.py:596-601 for this rank's latents: ``latents / scaling_factor`` -> ``vae.decode`` ->
+    ``(255 * (x / 2 + 0.5).clamp(0, 1)).to(uint8)``.  Returns (n, 3, 8h, 8w) uint8.  ``vae``: ldm.vae.AutoencoderKL.
+    compute_dtype bfloat16 = what ``accelerator.autocast()`` around ``generate`` gives the reference (:626); None = the
+    latents' own dtype."""
+    from .vae import to_uint8
+    z = latents / vae.config.scaling_factor
+    if compute_dtype == torch.bfloat16 and z.dtype != torch.bfloat16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            img = vae.decode(z, return_dict=False, micro_batch=micro_batch)[0]
+    else:
+        img = vae.decode(z, return_dict=False, micro_batch=micro_batch)[0]
+    return to_uint8(img)
+
+
+def generate_images(denoiser: Callable, scheduler, vae, ctx: torch.Tensor, **kw) -> torch.Tensor:
+    """``generate`` (train_latent_diffusion.py:529-607) from the text embeddings on: the reverse loop for this rank's
+    shard, then the decoder and the uint8 conversion.  Keyword arguments are ``sample_latents``'."""
+    return decode_images(vae, sample_latents(denoiser, scheduler, ctx, **kw))
 
 
 def gather_latents(local: torch.Tensor, n: int, rank: int, world: int, group=None) -> torch.Tensor:

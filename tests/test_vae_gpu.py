@@ -187,3 +187,20 @@ def test_rejects_cpu_tensors_and_wrong_channel_counts():
         m.decode(torch.zeros(1, 3, 8, 8, device="cuda"))
     with pytest.raises(NotImplementedError):
         m.encode(torch.zeros(1, 3, 64, 64, device="cuda"))
+
+
+def test_decode_images_is_the_reference_tail_of_generate():
+    """ldm/sampling.py::decode_images = :596-601: divide by the scaling factor, decode (bf16 autocast), convert to uint8."""
+    from ldm import sampling
+    from ldm.vae import to_uint8
+    m, cfg, sd = _vae(SMALL)
+    lat = seeded((3, 4, 8, 8), 51).cuda()
+    got = sampling.decode_images(m, lat, micro_batch=2)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        img = m.decode(lat / m.config.scaling_factor, return_dict=False)[0]
+    want = to_uint8(img)
+    assert got.dtype == torch.uint8 and got.shape == (3, 3, 64, 64)
+    lvl = (got.int() - want.int()).abs()
+    assert int(lvl.max()) <= 2            # micro-batches of 2 vs one batch of 3: same arithmetic, tile choice may differ
+    ref = vref.to_uint8(vref.decode(_f64(sd), cfg, (lat.cpu() / cfg.scaling_factor).double()).float())
+    assert float((got.cpu().int() - ref.int()).abs().float().mean()) < 1.5

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--micro-batch", type=int, default=32)
     ap.add_argument("--guidance", type=float, default=None, help="classifier-free guidance scale (2 forwards' worth per step)")
+    ap.add_argument("--decode", action="store_true", help="also run the VAE decoder + uint8 conversion on the final latents "
+                    "(train_latent_diffusion.py:596-601) and report the whole generate() job in images/s")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -64,6 +66,24 @@ def main():
         local = sampling.sample_latents(net, DDPMScheduler(device=dev), ctx, **kw)
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
+    extra = {}
+    if args.decode:
+        from ldm.vae import AutoencoderKL
+        with torch.device("meta"):
+            vae = AutoencoderKL()
+        vae = vae.to_empty(device=dev)
+        init_weights_(vae, seed=77)
+        vae.eval()
+        z = local.clamp(-4, 4)                  # random weights do not denoise: keep the decoder's input in a latent's range
+        sampling.decode_images(vae, z[:2])      # warm-up (packs the filters)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        images = sampling.decode_images(vae, z, micro_batch=8)
+        torch.cuda.synchronize(dev)
+        dec = sampling.max_over_ranks(time.perf_counter() - t1, dev, world)
+        assert images.dtype == torch.uint8 and images.shape[1:] == (3, 512, 512)
+        extra = {"decode_seconds": round(dec, 3), "decode_images_per_s": round(args.latents / dec, 1),
+                 "generate_images_per_s": round(args.latents / (sampling.max_over_ranks(elapsed, dev, world) + dec), 2)}
     elapsed = sampling.max_over_ranks(elapsed, dev, world)
     full = sampling.gather_latents(local, args.latents, rank, world)
     if rank == 0:
@@ -71,7 +91,7 @@ def main():
                           "value": round(args.latents * args.steps / elapsed, 2), "unit": "img-steps/s", "n_gpus": world,
                           "latents": args.latents, "steps": args.steps, "seconds": round(elapsed, 3), "dtype": "bf16",
                           "guidance": args.guidance, "micro_batch": args.micro_batch, "scaling": "strong",
-                          "finite": bool(torch.isfinite(full).all()), "latent_abs_mean": round(float(full.abs().mean()), 6)}), flush=True)
+                          "finite": bool(torch.isfinite(full).all()), "latent_abs_mean": round(float(full.abs().mean()), 6), **extra}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
