@@ -169,6 +169,11 @@ def main():
         dom = max(per, key=lambda k: per[k][2])
         n_l, fl, tt = per[dom]
         achieved = fl / tt
+        # HBM bytes per launch of the dominant kernel: not measurable from inside the process; the figure is the one the
+        # separate rocprofv3 --pmc passes over this same command gave (FETCH_SIZE, doubled per the gfx950 correction, +
+        # WRITE_SIZE; profiles/r1_v7_pmc_per_kernel.md), reported only for the shape it was measured on.
+        pmc_traffic = {"conv_gemm_bf16_kernel<256,160,64>": 288.5e6}
+        traffic = pmc_traffic.get(dom) if (LAT == 64 and B == BATCH) else None
         out = {
             "metric": f"UNet denoise img-steps/sec at {LAT}x{LAT} latents",
             "value": round(value, 2), "unit": "img-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -183,7 +188,9 @@ def main():
                        "end_to_end_frac_of_mfma_peak": round(flops_per_image * B / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
                        "gemm_kernel_share_of_step": round(gemm_time / elapsed, 3)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": traffic,
+                         "traffic_note": "HBM+Infinity-Cache bytes per launch from committed PMC passes "
+                                         "(profiles/r1_v7_pmc_per_kernel.md), not collected live",
                          "launches": n_l, "avg_launch_us": round(1e6 * tt / n_l, 1),
                          "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 2),
                          "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),

@@ -102,15 +102,16 @@ conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const floa
     wl[tap * cb + co] = w[(size_t)co0 * TAPS + i];
   }
   __syncthreads();
-  const int chunks = cb >> 3;
-  const int64_t total = (int64_t)batch * h * wd * chunks;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int ch = (int)(i % chunks);
-    const int64_t pix = i / chunks;
-    const int ow = (int)(pix % wd);
-    const int oh = (int)((pix / wd) % h);
-    const int b = (int)(pix / ((int64_t)wd * h));
+  const unsigned chunks = cb >> 3;
+  const unsigned total = (unsigned)batch * h * wd * chunks;    // < 2^31 (checked on the host): 32-bit divisions
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const unsigned pix = i / chunks;
+    const int ch = (int)(i - pix * chunks);
+    const unsigned prow = pix / (unsigned)wd;
+    const int ow = (int)(pix - prow * wd);
+    const int b = (int)(prow / (unsigned)h);
+    const int oh = (int)(prow - (unsigned)b * h);
     float acc[8];
     load8(bias + co0 + ch * 8, acc);
 #pragma unroll
@@ -130,7 +131,7 @@ conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const floa
         }
       }
     }
-    store8(out + pix * cout + co0 + ch * 8, acc);
+    store8(out + (size_t)pix * cout + co0 + ch * 8, acc);
   }
 }
 
@@ -208,21 +209,24 @@ __global__ void __launch_bounds__(256)
 conv_out_lanes_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
                       int batch, int cin, int h, int wd) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* wl = reinterpret_cast<float*>(smem_raw);  // [9][cin][COUT]
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [9][COUT][rowf]: chunk c of a row at c*8 + (c>>3)*4 floats, so the 16
+  const int rowf = cin + (cin >> 6) * 4 + 4;       // chunks a 16-lane group reads at once fall into 16 different bank quads
   for (int i = threadIdx.x; i < 9 * cin * COUT; i += 256) {
-    const int co = i % COUT, c = (i / COUT) % cin, tap = i / (COUT * cin);
-    wl[i] = w[((size_t)co * cin + c) * 9 + tap];   // w is [COUT][cin][3][3]
+    const int tap = i % 9, c = (i / 9) % cin, co = i / (9 * cin);   // w is [COUT][cin][3][3]: coalesced read
+    wl[(tap * COUT + co) * rowf + c + (c >> 6) * 4] = w[i];
   }
   __syncthreads();
   const int sub = threadIdx.x & 15;
   const int chunks = cin >> 3;
-  const int64_t npix = (int64_t)batch * h * wd;
-  const int64_t stride = (int64_t)gridDim.x * 16;
-  for (int64_t pix = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); pix - (threadIdx.x >> 4) < npix; pix += stride) {
+  const unsigned npix = (unsigned)batch * h * wd;  // < 2^31 (checked on the host): 32-bit divisions
+  const unsigned stride = gridDim.x * 16;
+  for (unsigned base = blockIdx.x * 16; base < npix; base += stride) {
+    const unsigned pix = base + (threadIdx.x >> 4);
     const bool live = pix < npix;                  // whole 16-lane groups stay in the loop for the butterfly
-    const int ow = (int)(pix % wd);
-    const int oh = (int)((pix / wd) % h);
-    const int64_t b = pix / ((int64_t)wd * h);
+    const unsigned prow = pix / (unsigned)wd;
+    const int ow = (int)(pix - prow * wd);
+    const int b = (int)(prow / (unsigned)h);
+    const int oh = (int)(prow - (unsigned)b * h);
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
@@ -233,16 +237,19 @@ conv_out_lanes_kernel(const TX* __restrict__ x, const float* __restrict__ w, con
         for (int kw = 0; kw < 3; ++kw) {
           const int iw = ow + kw - 1;
           if (iw < 0 || iw >= wd) continue;
-          const TX* row = x + ((b * h + ih) * wd + iw) * cin;
-          const float* wt = wl + (size_t)(kh * 3 + kw) * cin * COUT;
+          const TX* row = x + (((size_t)b * h + ih) * wd + iw) * cin;
+          const float* wt = wl + (size_t)(kh * 3 + kw) * COUT * rowf;
           for (int ch = sub; ch < chunks; ch += 16) {
             float v[8];
             load8(row + ch * 8, v);
-            const float* wp = wt + ch * 8 * COUT;
+            const float* wp = wt + ch * 8 + (ch >> 3) * 4;
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int co = 0; co < COUT; ++co) {
+              float wv[8];
+              load8(wp + co * rowf, wv);
 #pragma unroll
-              for (int co = 0; co < COUT; ++co) acc[co] += v[j] * wp[j * COUT + co];
+              for (int j = 0; j < 8; ++j) acc[co] += v[j] * wv[j];
+            }
           }
         }
       }
@@ -256,7 +263,7 @@ conv_out_lanes_kernel(const TX* __restrict__ x, const float* __restrict__ w, con
       float r = acc[0];
 #pragma unroll
       for (int co = 1; co < COUT; ++co) r = sub == co ? acc[co] : r;
-      Elem<TO>::st(out + ((b * COUT + sub) * h + oh) * wd + ow, r + bias[sub]);
+      Elem<TO>::st(out + (((size_t)b * COUT + sub) * h + oh) * wd + ow, r + bias[sub]);
     }
   }
 }
@@ -331,7 +338,7 @@ template <typename TX, typename TO>
 static int conv_in_dispatch(const void* x, const float* w, const float* bias, void* out, int batch, int cin, int h,
                             int wd, int cout, hipStream_t st) {
   const int64_t npix = (int64_t)batch * h * wd;
-  if (cin == 4 && cout % 8 == 0 && aligned16(out) && aligned16(bias)) {
+  if (cin == 4 && cout % 8 == 0 && aligned16(out) && aligned16(bias) && npix * (cout / 8) < (1LL << 31)) {
     const int cblk = cout <= 448 ? cout : 256;   // output channels per workgroup: 36 * cblk floats of LDS (<= 64 KB)
     const int ny = (cout + cblk - 1) / cblk;
     int64_t nb = (npix * (cblk / 8) + 255) / 256;
@@ -365,8 +372,8 @@ static int conv_out_dispatch(const void* x, const float* w, const float* bias, v
                              int wd, int cout, hipStream_t st) {
   const int64_t npix = (int64_t)batch * h * wd;
   dim3 grid(blocks_for(npix)), block(256);
-  const size_t lds = (size_t)9 * cin * cout * sizeof(float);
-  if (npix >= 65536 && lds <= 65536 && cout <= 4) {   // large images: 16 lanes per pixel, filter in LDS
+  const size_t lds = (size_t)9 * cout * (cin + (cin >> 6) * 4 + 4) * sizeof(float);
+  if (npix >= 65536 && npix < (1LL << 31) && lds <= 65536 && cout <= 4) {   // large images: 16 lanes per pixel, filter in LDS
     int64_t nb = (npix + 15) / 16;
     if (nb > 8192) nb = 8192;                        // grid-stride: the LDS filter image is filled once per workgroup
     const dim3 g((unsigned)nb);
