@@ -44,22 +44,43 @@ class Tape:
         their owners split them and put the parts under the parameters' names."""
         if self.sink is not None and key in self.sink.params and self.sink.params[key].requires_grad:
             g = self.sink.put(key, g)           # -> view of a flat bucket, averaged once the pass finishes
-        self.grads[key] = g if key not in self.grads else self.grads[key] + g
+        if key in self.grads:
+            g = self.grads[key] + g.reshape(self.grads[key].shape)
+        self.grads[key] = g
 
-    def weight_grad(self, name: str, a0, dy, *, a1=None, ksize=1, stride=1, upsample=False):
-        return ops.conv_wgrad(a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample)
+    def weight_grad(self, name: str, a0, dy, *, a1=None, ksize=1, stride=1, upsample=False, in_place=True):
+        """Weight gradient of layer ``name``; with a gradient sink it is written straight into the parameter's slice of
+        the sink's flat bucket (no copy between the kernel and the optimizer)."""
+        out = None
+        if in_place and self.sink is not None:
+            c = a0.shape[-1] + (0 if a1 is None else a1.shape[-1])
+            shape = (dy.shape[-1], c) if (ksize == 1 and not upsample and stride == 1) else (dy.shape[-1], c, ksize, ksize)
+            out = self.sink.dest(name + ".weight", shape)
+        return ops.conv_wgrad(a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample, out=out,
+                              accumulate=False)
 
-    def bias_grad(self, dy: torch.Tensor) -> torch.Tensor:
-        return ops.colsum(dy).view(-1)
+    def bias_grad(self, dy: torch.Tensor, key: Optional[str] = None) -> torch.Tensor:
+        """Column sums of dy; ``key`` (a parameter name): written straight into its gradient-bucket slice when there is one."""
+        out = self.sink.dest(key, (1, dy.shape[-1])) if (key is not None and self.sink is not None) else None
+        return ops.colsum(dy, out=out, accumulate=False).view(-1)
+
+    def norm_dest(self, prefix: str, channels: int) -> dict:
+        """dgamma / dbeta destinations of a norm layer's backward inside the gradient buckets (or nothing)."""
+        if self.sink is None:
+            return {}
+        dg, db = self.sink.dest(prefix + ".weight", (channels,)), self.sink.dest(prefix + ".bias", (channels,))
+        return {} if dg is None or db is None else dict(dgamma=dg, dbeta=db, accumulate=False)
 
     def add_ctx_grad(self, g: torch.Tensor):
         self.dctx = g if self.dctx is None else ops.add(self.dctx, g)
 
 
 def glu_rows_to_checkpoint(g: torch.Tensor) -> torch.Tensor:
-    """Rows in ldm_pack_weight(glu_pairs) order (blocks of 16 values then their 16 gates) -> [values | gates]."""
+    """Rows in ldm_pack_weight(glu_pairs) order (blocks of 16 values then their 16 gates) -> [values | gates].
+    Returns a strided view whose element order is the checkpoint's: whoever stores it (Tape.put -> the gradient bucket,
+    or the reshape at the autograd boundary) makes the one copy."""
     n = g.shape[0]
-    return g.view(n // 32, 2, 16, *g.shape[1:]).transpose(0, 1).reshape(g.shape)
+    return g.view(n // 32, 2, 16, *g.shape[1:]).transpose(0, 1)
 
 
 def glu_rows_to_packed(w: torch.Tensor) -> torch.Tensor:
@@ -78,10 +99,10 @@ def conv_train(T: Tape, name: str, a0, *, a1=None, ksize=1, stride=1, upsample=F
     in_hw = (a0.shape[1], a0.shape[2]) if a0.dim() == 4 else None
 
     def bwd(dy, need_dx=True, add=None, bias_from=None):
-        gw = T.weight_grad(name, a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample)
+        gw = T.weight_grad(name, a0, dy, a1=a1, ksize=ksize, stride=stride, upsample=upsample, in_place=grad_map is None)
         T.put(name + ".weight", gw if grad_map is None else grad_map(gw))
         if has_bias:
-            gb = T.bias_grad(dy) if bias_from is None else bias_from
+            gb = (T.bias_grad(dy, name + ".bias" if grad_map is None else None)) if bias_from is None else bias_from
             T.put(name + ".bias", gb if grad_map is None else grad_map(gb))
         if not need_dx:
             return None
@@ -106,14 +127,16 @@ def resnet_train(T: Tape, n: str, r, x, skip, rowvec):
 
     def bwd(dout):
         da2 = o_bwd(dout)
-        dv, dg, db = ops.groupnorm_backward(v, st2, P[_j(n, "layers.0.g")], P[_j(n, "layers.0.b")], g, da2, silu=True)
+        dv, dg, db = ops.groupnorm_backward(v, st2, P[_j(n, "layers.0.g")], P[_j(n, "layers.0.b")], g, da2, silu=True,
+                                            **T.norm_dest(_j(n, "layers.0"), v.shape[-1]))
         T.put(_j(n, "layers.0.weight"), dg)
         T.put(_j(n, "layers.0.bias"), db)
         drow = ops.colsum(dv, segments=B)                                   # (B, Cout) float32
         da = v_bwd(dv, bias_from=ops.colsum(drow).view(-1))
         dres = sc_bwd(dout) if sc_bwd is not None else dout                 # gradient arriving over the shortcut
         dxc, dg, db = ops.groupnorm_backward(x, st1, P[_j(n, "visual.0.g")], P[_j(n, "visual.0.b")], g, da, a1=skip,
-                                             silu=True, add=dres, split=True)
+                                             silu=True, add=dres, split=True,
+                                             **T.norm_dest(_j(n, "visual.0"), da.shape[-1]))
         T.put(_j(n, "visual.0.weight"), dg)
         T.put(_j(n, "visual.0.bias"), db)
         if skip is None:
@@ -168,7 +191,7 @@ def transformer_block_train(T: Tape, n: str, blk, x, ctx):
         return ops.layernorm(t, P[_j(n, key + ".g")], P[_j(n, key + ".b")])
 
     def ln_bwd(key, t, dy, add=None):
-        dx, dg, db = ops.layernorm_backward(t, P[_j(n, key + ".g")], dy, add=add)
+        dx, dg, db = ops.layernorm_backward(t, P[_j(n, key + ".g")], dy, add=add, **T.norm_dest(_j(n, key), t.shape[-1]))
         T.put(_j(n, key + ".weight"), dg)
         T.put(_j(n, key + ".bias"), db)
         return dx
@@ -214,7 +237,7 @@ def transformer_model_train(T: Tape, n: str, t, h, ctx):
             dx = b(dx)
         dx0 = in_bwd(dx)
         dh, dg, db = ops.groupnorm_backward(h, st, P[_j(n, "norm.g")], P[_j(n, "norm.b")], t.norm_num_groups,
-                                            dx0.view(B, H, W, C))
+                                            dx0.view(B, H, W, C), **T.norm_dest(_j(n, "norm"), C))
         T.put(_j(n, "norm.weight"), dg)
         T.put(_j(n, "norm.bias"), db)
         return dh
@@ -360,7 +383,8 @@ def unet_train(T: Tape, net, sample, t_f32, ctx, need_dsample: bool):
 
     def bwd(dout):
         da = cout_bwd(dout)
-        dh, dg, db = ops.groupnorm_backward(hf, stf, P["final_conv.0.g"], P["final_conv.0.b"], g, da, silu=True)
+        dh, dg, db = ops.groupnorm_backward(hf, stf, P["final_conv.0.g"], P["final_conv.0.b"], g, da, silu=True,
+                                            **T.norm_dest("final_conv.0", da.shape[-1]))
         T.put("final_conv.0.weight", dg)
         T.put("final_conv.0.bias", db)
         while tape:
@@ -429,6 +453,9 @@ class TrainFunction(torch.autograd.Function):
         for j, (name, (dtype, shape)) in enumerate(zip(ctx.names, ctx.param_meta)):
             g = grads.get(name)
             if g is None or not ctx.needs_input_grad[3 + ctx.n_in + j]:
+                res.append(None)
+            elif sink is not None and dtype == torch.float32 and sink.owns(name, g) and sink.params[name].grad is None:
+                sink.params[name].grad = g.view(shape)     # the bucket slice IS the gradient (gradient_as_bucket_view)
                 res.append(None)
             else:
                 g = g.reshape(shape).to(dtype)

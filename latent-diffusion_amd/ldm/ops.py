@@ -206,9 +206,10 @@ def sum2x2(x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Te
 
 
 def conv_wgrad(a0: torch.Tensor, dy: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
-               upsample: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               upsample: bool = False, out: Optional[torch.Tensor] = None, accumulate: Optional[bool] = None) -> torch.Tensor:
     """Weight gradient of conv_gemm(a0, w, a1=..., ksize=..., stride=..., upsample=...): float32, checkpoint layout
-    ([N, C0+C1, k, k], or [N, C] for ksize == 1 matrices).  ``out``: an existing gradient to accumulate into."""
+    ([N, C0+C1, k, k], or [N, C] for ksize == 1 matrices).  ``out``: an existing gradient to accumulate into, or
+    (accumulate=False) a buffer to overwrite, e.g. the parameter's slice of a flat gradient bucket."""
     _gpu(a0, a1, dy, out)
     if a0.dtype != dy.dtype or (a1 is not None and a1.dtype != a0.dtype):
         raise TypeError("conv_wgrad: activations and output gradients must share one dtype")
@@ -232,8 +233,10 @@ def conv_wgrad(a0: torch.Tensor, dy: torch.Tensor, *, a1: Optional[torch.Tensor]
         shape = (n, c0 + c1, ksize, ksize)
     if dy.numel() != batch * hout * wout * n:
         raise ValueError(f"conv_wgrad: dy has {dy.numel()} elements, expected {batch * hout * wout}x{n}")
-    accumulate = out is not None
+    if accumulate is None:
+        accumulate = out is not None
     if out is None:
+        accumulate = False
         out = torch.empty(shape, dtype=torch.float32, device=a0.device)
     elif out.dtype != torch.float32 or tuple(out.shape) != shape or not out.is_contiguous():
         raise ValueError(f"conv_wgrad: out must be a contiguous float32 tensor of shape {shape}")
@@ -354,9 +357,9 @@ def _bwd_workspace(device, nfloats: int) -> torch.Tensor:
 
 
 def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=False, add=None, dgamma=None, dbeta=None,
-                       split=False):
+                       split=False, accumulate=None):
     """Backward of groupnorm(a0, ..., a1=a1, silu=silu): returns (dx over all c0+c1 channels [+ add], dgamma, dbeta).
-    dgamma / dbeta given: accumulated into (float32).  split (two sources): dx is the pair (dx0 (.., c0), dx1 (.., c1)),
+    dgamma / dbeta given: accumulated into (float32), or overwritten with accumulate=False.  split (two sources): dx is the pair (dx0 (.., c0), dx1 (.., c1)),
     each dense -- the concat gradient is split where it is produced."""
     _gpu(a0, a1, stats, gamma, beta, dy, add, dgamma, dbeta)
     B = a0.shape[0]
@@ -367,8 +370,10 @@ def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=Fals
         raise ValueError("groupnorm_backward: dy must be contiguous (.., c0+c1) in the activation dtype")
     if add is not None and (not add.is_contiguous() or add.shape != dy.shape):
         raise ValueError("groupnorm_backward: add must be contiguous with dy's shape")
-    accumulate = dgamma is not None
-    if not accumulate:
+    if accumulate is None:
+        accumulate = dgamma is not None
+    if dgamma is None:
+        accumulate = False
         dgamma = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
         dbeta = torch.empty(c0 + c1, dtype=torch.float32, device=a0.device)
     if split and a1 is not None:
@@ -386,13 +391,15 @@ def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=Fals
     return ((dx, dx1) if dx1 is not None else dx), dgamma, dbeta
 
 
-def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None, dbeta=None):
+def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None, dbeta=None, accumulate=None):
     """Backward of layernorm(x, gamma, beta): returns (dx [+ add], dgamma, dbeta)."""
     _gpu(x, gamma, dy, add, dgamma, dbeta)
     cols = x.shape[-1]
     rows = x.numel() // cols
-    accumulate = dgamma is not None
-    if not accumulate:
+    if accumulate is None:
+        accumulate = dgamma is not None
+    if dgamma is None:
+        accumulate = False
         dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
         dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
     dx = torch.empty_like(x)
@@ -405,16 +412,21 @@ def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None
     return dx, dgamma, dbeta
 
 
-def colsum(x: torch.Tensor, segments: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """float32 column sums per segment of consecutive rows: (segments, n).  out given: accumulated into."""
+def colsum(x: torch.Tensor, segments: int = 1, out: Optional[torch.Tensor] = None, accumulate: Optional[bool] = None) -> torch.Tensor:
+    """float32 column sums per segment of consecutive rows: (segments, n).  out given: accumulated into (or overwritten
+    with accumulate=False)."""
     _gpu(x, out)
     n = x.shape[-1]
     rows = x.numel() // n
     if rows % segments:
         raise ValueError("colsum: rows not divisible by segments")
-    accumulate = out is not None
+    if accumulate is None:
+        accumulate = out is not None
     if out is None:
+        accumulate = False
         out = torch.empty((segments, n), dtype=torch.float32, device=x.device)
+    elif out.dtype != torch.float32 or out.numel() != segments * n or not out.is_contiguous():
+        raise ValueError("colsum: out must be a contiguous float32 tensor of segments * n elements")
     lib = _lib.load()
     with torch.cuda.device(x.device):
         ws = _bwd_workspace(x.device, lib.ldm_colsum_workspace_floats(segments, n))

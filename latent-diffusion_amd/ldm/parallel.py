@@ -5,9 +5,11 @@ torch DDP when launched with more than one process, and DDP's reducer all-reduce
 produces them (``accelerator.backward`` :1119, ``accumulate`` / ``no_sync`` :1032).  The HIP UNet is ONE autograd node
 (ldm/_train.py), so torch DDP would see every gradient at the same instant, after the whole backward.  The overlap
 therefore lives inside the hand-scheduled backward: ``Tape.put`` hands each finished parameter gradient to a
-``GradReducer``, which packs it (pre-divided by the world size) into a flat bucket and launches
-``torch.distributed.all_reduce(bucket, async_op=True)`` -- RCCL on its own stream -- as soon as a bucket is full, while
-the backward kernels of earlier layers keep running.  The node's backward ends by waiting for the outstanding buckets.
+``GradReducer``, whose flat buckets ARE the gradients (as DDP's ``gradient_as_bucket_view``): the weight-gradient kernels
+write their result straight into the parameter's bucket slice, ``.grad`` is set to that slice, and
+``torch.distributed.all_reduce(bucket, AVG, async_op=True)`` -- RCCL on its own stream -- is launched as soon as a bucket
+is full, while the backward kernels of earlier layers keep running.  The node's backward ends by waiting for the
+outstanding buckets.  No gradient is copied on its way from the kernel to the optimizer.
 
 xGMI is point-to-point (7 links per GPU): a ring all-reduce is bound by one link, so buckets are large (64 MiB default:
 few, long transfers; 3.44 GB of float32 gradients = 52 buckets) and there is no attempt to mimic NCCL/NVSwitch tuning.
@@ -45,6 +47,7 @@ class GradReducer:
         self.handles: List = []
         self.pending: Dict[str, torch.Tensor] = {}
         self.launched = 0                         # collectives launched in the current pass (tests / bench)
+        self._post_scale: List[int] = []
 
     # -------------------------------------------------------------------------------------------- layout
     def _build(self, device, dtype):
@@ -73,40 +76,64 @@ class GradReducer:
     def begin(self):
         self.handles, self.pending, self.launched = [], {}, 0
         self.fill = [0] * len(self.buckets)
+        self._post_scale: List[int] = []
+
+    def _view(self, name: str) -> torch.Tensor:
+        bi, off, n = self.slot[name]
+        return self.buckets[bi][off:off + n]
+
+    def dest(self, name: str, shape) -> Optional[torch.Tensor]:
+        """Zero-copy path (DDP's ``gradient_as_bucket_view``): the bucket slice of ``name``, shaped ``shape``, for a
+        producer that can write this pass's gradient in place and then hands the same tensor to ``put``.  None when the
+        gradient has to be combined with an existing ``.grad`` or the layout is not fixed yet."""
+        if name not in self.slot or self.params[name].grad is not None:
+            return None
+        return self._view(name).view(shape)
+
+    def owns(self, name: str, g: torch.Tensor) -> bool:
+        return name in self.slot and g.dtype == torch.float32 and g.data_ptr() == self._view(name).data_ptr()
 
     def put(self, name: str, g: torch.Tensor) -> torch.Tensor:
-        """Takes this rank's finished gradient of parameter ``name``; returns the tensor that will hold the average
-        once ``finish()`` has run."""
+        """Takes this rank's finished gradient of parameter ``name`` (any shape with the parameter's element order;
+        strided views are copied once, straight into the bucket); returns the tensor that will hold the average once
+        ``finish()`` has run."""
         p = self.params[name]
-        g = g.reshape(p.shape)                     # 1x1 conv filters arrive as matrices
         acc = p.grad                               # micro-batches accumulated under no_sync()
         if acc is not None:
             p.grad = None                          # the reduced sum becomes the gradient of this backward
         if not self.slot:                          # first pass: record the order, reduce at the end
             self.order.append(name)
-            g = g.to(torch.float32)
+            g = g.reshape(p.shape).to(torch.float32)
             self.pending[name] = g if acc is None else g + acc.to(torch.float32)
             return self.pending[name]
         if name not in self.slot:                  # a parameter that had no gradient in the first pass
-            g = g.to(torch.float32)
+            g = g.reshape(p.shape).to(torch.float32)
             self.pending[name] = (g if acc is None else g + acc.to(torch.float32)) * (1.0 / self.world)
             return self.pending[name]
-        bi, off, n = self.slot[name]
-        view = self.buckets[bi][off:off + n].view(g.shape)
+        bi = self.slot[name][0]
+        flat = self._view(name)
         if acc is None:
-            torch.mul(g, 1.0 / self.world, out=view)
-        else:
-            torch.add(g, acc, out=view)
-            view.mul_(1.0 / self.world)
+            if not (g.dtype == torch.float32 and g.data_ptr() == flat.data_ptr()):   # else: written in place (dest)
+                flat.view(g.shape).copy_(g)
+        else:                                      # acc may be this very slice (grads zeroed in place, or never zeroed)
+            torch.add(g.reshape(p.shape), acc.reshape(p.shape), out=flat.view(p.shape))
         self.fill[bi] += 1
         if self.fill[bi] == self.size[bi]:
             self._launch(bi)
-        return view
+        return flat.view(p.shape)
 
-    def _launch(self, bi: int):
+    def _launch(self, bi: int, prescaled: bool = False):
+        """Average bucket ``bi`` over the group.  RCCL averages in the collective; backends without AVG (gloo) sum and
+        the bucket is scaled when the pass finishes."""
         self.launched += 1
         if self.world > 1:
-            self.handles.append(dist.all_reduce(self.buckets[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            op = dist.ReduceOp.SUM
+            if not prescaled:
+                if dist.get_backend(self.group) == "nccl":
+                    op = dist.ReduceOp.AVG
+                else:
+                    self._post_scale.append(bi)
+            self.handles.append(dist.all_reduce(self.buckets[bi], op=op, group=self.group, async_op=True))
 
     def finish(self) -> Dict[str, torch.Tensor]:
         """Completes the pass: after this the tensors returned by put() hold the averaged gradients (stream-ordered on
@@ -116,13 +143,12 @@ class GradReducer:
             any_g = next(iter(self.pending.values()))
             self._build(any_g.device, torch.float32)
             for name in self.order:
-                bi, off, n = self.slot[name]
-                view = self.buckets[bi][off:off + n].view(self.pending[name].shape)
+                view = self._view(name).view(self.pending[name].shape)
                 torch.mul(self.pending[name], 1.0 / self.world, out=view)
                 replaced[name] = view
             self.pending = {}
             for bi in range(len(self.buckets)):
-                self._launch(bi)
+                self._launch(bi, prescaled=True)
         else:
             for bi in range(len(self.buckets)):   # parameters without a gradient this pass leave a bucket short
                 if 0 < self.fill[bi] < self.size[bi]:
@@ -135,6 +161,9 @@ class GradReducer:
         for h in self.handles:
             h.wait()
         self.handles = []
+        for bi in self._post_scale:
+            self.buckets[bi].mul_(1.0 / self.world)
+        self._post_scale = []
         return replaced
 
 

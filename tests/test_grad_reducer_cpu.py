@@ -60,6 +60,34 @@ def _run_passes(rank, world):
         assert params[k].grad is None
         assert torch.allclose(out[k], _mean(k, world, 2) + _mean(k, world, 7), atol=1e-6), k
     assert params["c.weight"].grad is not None            # untouched: it took no part in this backward
+    params["c.weight"].grad = None
+    # pass 3: zero-copy form -- producers write into the bucket slices (dest), put() recognises them and copies nothing;
+    # a strided gradient (the GLU row permutation) is copied once, straight into its slice
+    red.begin()
+    out = {}
+    for k in ORDER:
+        g = _grad(k, rank, 3)
+        if k == "a.weight":                                # arrives as a transposed view with the parameter's element order
+            out[k] = red.put(k, g.view(5, 8, 30).transpose(0, 1).contiguous().transpose(0, 1))
+            continue
+        d = red.dest(k, g.shape)
+        assert d is not None and d.data_ptr() == red._view(k).data_ptr()
+        d.copy_(g)
+        out[k] = red.put(k, d)
+        assert out[k].data_ptr() == d.data_ptr()
+    red.finish()
+    for k in ORDER:
+        assert red.owns(k, out[k])
+        assert torch.allclose(out[k], _mean(k, world, 3), atol=1e-6), k
+        params[k].grad = out[k]                            # what the autograd boundary does (gradient_as_bucket_view)
+    # pass 4: the gradients were not cleared and ARE the bucket slices: dest() refuses, put() accumulates in place
+    red.begin()
+    for k in ORDER:
+        assert red.dest(k, SHAPES[k]) is None
+        out[k] = red.put(k, _grad(k, rank, 4))
+    red.finish()
+    for k in ORDER:
+        assert torch.allclose(out[k], _mean(k, world, 3) + _mean(k, world, 4), atol=1e-6), k
     return True
 
 
