@@ -31,16 +31,21 @@ pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout,
 //   dgrad[ci][taps-1-tap][o']   row pitch dgrad_ld (>= cout: several filters may share one fused dgrad matrix): the filter of
 //                               the input-gradient pass -- in/out transposed, taps rotated by 180 degrees.
 // One workgroup moves a 32 (o') x 32 (ci) x taps block through LDS; global runs are 32 x taps floats in, 32 elements out.
-template <typename T>
+// VEC4 (bf16 only; cout, cin, dgrad_ld multiples of 4, destinations 8-byte aligned): a lane stores 4 packed elements.
+// TAPS = 1 / 9 (0: any, from the argument): with the tap count known the trip counts are constants, so all of a thread's
+// global loads (4 / 36) are in flight before the first LDS store -- with a run-time count the loop was one load, one
+// store, one HBM latency per iteration, and the whole repack ran at 2 TB/s.
+template <typename T, bool VEC4, int TAPS>
 __global__ void __launch_bounds__(256)
-pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad, int cout, int cin, int taps,
+pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad, int cout, int cin, int taps_arg,
                         int glu, long long dgrad_ld) {
   extern __shared__ float tile[];                       // [32 o'][32*taps + 1]
+  const int taps = TAPS ? TAPS : taps_arg;
   const int ost = 32 * taps + 1;
   const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int half = cout >> 1;
   const int run = 32 * taps;                            // floats per source row segment
-  for (int i = threadIdx.x; i < 32 * run; i += 256) {
+  auto fetch = [&](int i) {
     const int ol = i / run, k = i - ol * run;           // k = (ci_local, tap) flattened as in the source
     const int op = o0 + ol;
     const int ci = c0 + k / taps;
@@ -50,9 +55,57 @@ pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* _
       if (glu) { const int blk = op >> 5, w = op & 31; o = w < 16 ? blk * 16 + w : half + blk * 16 + (w - 16); }
       v = src[((long long)o * cin + c0) * taps + k];
     }
-    tile[ol * ost + k] = v;
+    return v;
+  };
+  if constexpr (TAPS != 0) {
+    constexpr int N = 32 * 32 * TAPS / 256;
+    float v[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) v[j] = fetch(threadIdx.x + j * 256);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int i = threadIdx.x + j * 256;
+      const int ol = i / run;
+      tile[ol * ost + (i - ol * run)] = v[j];
+    }
+  } else {
+    for (int i = threadIdx.x; i < 32 * run; i += 256) {
+      const int ol = i / run;
+      tile[ol * ost + (i - ol * run)] = fetch(i);
+    }
   }
   __syncthreads();
+  if constexpr (VEC4) {
+    if (fwd != nullptr) {
+      for (int i = threadIdx.x; i < 8 * run; i += 256) { // (o', tap, ci_local / 4) order
+        const int ol = i / (run >> 2), r = i - ol * (run >> 2);
+        const int tap = r >> 3, cl = (r & 7) * 4;
+        const int op = o0 + ol, ci = c0 + cl;
+        if (op < cout && ci < cin) {
+          const float* t = tile + ol * ost + cl * taps + tap;
+          uint2 v;
+          v.x = pack_bf16x2(t[0], t[taps]);
+          v.y = pack_bf16x2(t[2 * taps], t[3 * taps]);
+          *reinterpret_cast<uint2*>(fwd + ((long long)op * taps + tap) * cin + ci) = v;
+        }
+      }
+    }
+    if (dgrad != nullptr) {
+      for (int i = threadIdx.x; i < 8 * run; i += 256) { // (ci_local, tap', o' / 4) order
+        const int ol = (i & 7) * 4, r = i >> 3;
+        const int cl = r / taps, tp = r - cl * taps;
+        const int op = o0 + ol, ci = c0 + cl;
+        if (op < cout && ci < cin) {
+          const float* t = tile + ol * ost + cl * taps + (taps - 1 - tp);
+          uint2 v;
+          v.x = pack_bf16x2(t[0], t[ost]);
+          v.y = pack_bf16x2(t[2 * ost], t[3 * ost]);
+          *reinterpret_cast<uint2*>(dgrad + ((long long)ci * taps + tp) * dgrad_ld + op) = v;
+        }
+      }
+    }
+    return;
+  }
   if (fwd != nullptr) {
     for (int i = threadIdx.x; i < 32 * run; i += 256) { // (o', tap, ci_local) order
       const int ol = i / run, r = i - ol * run;
@@ -309,12 +362,18 @@ extern "C" int ldm_pack_weight_pair(const float* src, void* fwd, void* dgrad, in
   LDM_REQUIRE(grid.y <= 65535, "ldm_pack_weight_pair: cin too large");
   const size_t smem = (size_t)32 * (32 * taps + 1) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-  if (dst_dtype == LDM_BF16)
-    hipLaunchKernelGGL((pack_weight_pair_kernel<bf16_t>), grid, dim3(256), smem, st, src, (bf16_t*)fwd, (bf16_t*)dgrad, cout, cin, taps,
-                       glu_pairs, dgrad_ld);
-  else
-    hipLaunchKernelGGL((pack_weight_pair_kernel<float>), grid, dim3(256), smem, st, src, (float*)fwd, (float*)dgrad, cout, cin, taps,
-                       glu_pairs, dgrad_ld);
+  const bool vec4 = dst_dtype == LDM_BF16 && cout % 4 == 0 && cin % 4 == 0 && (dgrad == nullptr || dgrad_ld % 4 == 0) &&
+                    (reinterpret_cast<uintptr_t>(fwd) & 7) == 0 && (reinterpret_cast<uintptr_t>(dgrad) & 7) == 0;
+#define LDM_PACK_PAIR(T, V, TP) \
+  hipLaunchKernelGGL((pack_weight_pair_kernel<T, V, TP>), grid, dim3(256), smem, st, src, (T*)fwd, (T*)dgrad, cout, cin, taps, glu_pairs, dgrad_ld)
+  if (vec4) {
+    if (taps == 9) LDM_PACK_PAIR(bf16_t, true, 9); else if (taps == 1) LDM_PACK_PAIR(bf16_t, true, 1); else LDM_PACK_PAIR(bf16_t, true, 0);
+  } else if (dst_dtype == LDM_BF16) {
+    LDM_PACK_PAIR(bf16_t, false, 0);
+  } else {
+    LDM_PACK_PAIR(float, false, 0);
+  }
+#undef LDM_PACK_PAIR
   LDM_HIP_CHECK_LAUNCH("ldm_pack_weight_pair");
   return LDM_OK;
 }
