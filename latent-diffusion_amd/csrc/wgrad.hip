@@ -483,17 +483,27 @@ conv_wgrad_bf16_v2_kernel(const WgradParams p) {
 
 // dw[n][c_off + ci][tap] (+)= sum_s partial[s][n][tap*csrc + ci]   (fixed order; OIHW = the checkpoint layout).  A concat
 // layer's two sources are run as two passes: each fills its own channel range [c_off, c_off + csrc) of the ctot_dst channels.
+template <int TAPS>   // 1 / 9: constant divisions; 0: any (run-time)
 __global__ void __launch_bounds__(256)
-wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int K, int csrc, int taps, int splits,
+wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int K, int csrc, int taps_arg, int splits,
                   int accumulate, int c_off, int ctot_dst) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over this pass's dw elements, (n, ci, tap) order
-  if (idx >= (long long)N * K) return;
-  const int n = (int)(idx / K), rem = (int)(idx - (long long)n * K);
-  const int ci = rem / taps, tap = rem - ci * taps;
-  const size_t src = (size_t)n * K + (size_t)tap * csrc + ci;
+  const int taps = TAPS ? TAPS : taps_arg;
+  const unsigned total = (unsigned)N * (unsigned)K;                    // < 2^31 (checked on the host)
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;                // over this pass's dw elements, (n, ci, tap) order
+  if (idx >= total) return;
+  const unsigned n = idx / (unsigned)K, rem = idx - n * (unsigned)K;
+  const unsigned ci = rem / (unsigned)taps, tap = rem - ci * taps;
+  const float* src = partial + (size_t)n * K + (size_t)tap * csrc + ci;
   const size_t dst = ((size_t)n * ctot_dst + c_off + ci) * taps + tap;
+  const size_t sstride = (size_t)total;
   float v = accumulate ? dw[dst] : 0.f;
-  for (int s = 0; s < splits; ++s) v += partial[(size_t)s * N * K + src];
+  int s = 0;
+  for (; s + 3 < splits; s += 4) {                                     // four splits in flight; fixed order
+    const float p0 = src[(size_t)s * sstride], p1 = src[(size_t)(s + 1) * sstride];
+    const float p2 = src[(size_t)(s + 2) * sstride], p3 = src[(size_t)(s + 3) * sstride];
+    v = (((v + p0) + p1) + p2) + p3;
+  }
+  for (; s < splits; ++s) v += src[(size_t)s * sstride];
   dw[dst] = v;
 }
 
@@ -710,8 +720,15 @@ static int wgrad_run(const LdmConvGemm* d, const void* dy, float* dw, int accumu
   }
   LDM_HIP_CHECK_LAUNCH("ldm_conv_wgrad");
   const long long total = (long long)p.N * p.K;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot,
-                     d->ksize * d->ksize, p.splits, accumulate, c_off, ctot_dst);
+  LDM_REQUIRE(total < (1LL << 31), "ldm_conv_wgrad: filter of %lld elements", total);
+  const dim3 fgrid((unsigned)((total + 255) / 256));
+  const int ftaps = d->ksize * d->ksize;
+  if (ftaps == 9)
+    hipLaunchKernelGGL(wgrad_fold_kernel<9>, fgrid, dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, ftaps, p.splits, accumulate, c_off, ctot_dst);
+  else if (ftaps == 1)
+    hipLaunchKernelGGL(wgrad_fold_kernel<1>, fgrid, dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, ftaps, p.splits, accumulate, c_off, ctot_dst);
+  else
+    hipLaunchKernelGGL(wgrad_fold_kernel<0>, fgrid, dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, ftaps, p.splits, accumulate, c_off, ctot_dst);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_wgrad(fold)");
   return LDM_OK;
 }
