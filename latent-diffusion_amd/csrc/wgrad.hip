@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace ldm {
 
@@ -224,10 +225,11 @@ __device__ __forceinline__ int w2_swz(int row) { return T == 256 ? (row & 7) << 
 // FAST: stride 1, no upsample, and (1x1 or power-of-two extents) -- the per-step address arithmetic described below is
 // compiled out of the other path entirely (its registers spilled, and every scratch reload waits for vmcnt(0), i.e. for
 // all LDS-DMA in flight).  Single source only: concat layers run as two passes (wgrad_two_pass).
-template <int T0, int T1, int W0, int W1, bool FAST>
+template <int T0, int T1, int W0, int W1, int MODE>   // MODE 0: general; 1: fast (see above); 2: fast and 1x1
 __global__ void __launch_bounds__(512)
 conv_wgrad_bf16_v2_kernel(const WgradParams p) {
   constexpr bool TWO_SRC = false;
+  constexpr bool FAST = MODE != 0, ONE_TAP = MODE == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   static_assert(W0 * W1 == 8, "8 waves");
   constexpr unsigned OOB = 0x80000000u;
@@ -326,62 +328,84 @@ conv_wgrad_bf16_v2_kernel(const WgradParams p) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, 0, 0, 0);
   };
 
-  auto stage = [&](int slot, int step) {
+  // Running descriptor state (wave-uniform): stage() is called for consecutive steps, so bases and remaining byte counts
+  // advance by one step per call -- a handful of scalar adds.  (Recomputing them per call from the step index cost ~80
+  // scalar instructions of 64-bit arithmetic and, with the branches around it, made a wave's serial staging code longer
+  // than its 32 MFMAs: the matrix cores idled ~20 % of every step.)
+  const long long dy_step = (long long)W2_MS * p.N * 2;
+  const long long a_step = (long long)W2_MS * p.c0 * 2;    // fast path: a step is 32 pixels of the input, too
+  const char* dy_ptr = static_cast<const char*>(p.dy) + (long long)step_begin * dy_step;
+  long long dy_left = ((long long)p.M - (long long)step_begin * W2_MS) * p.N * 2;
+  // fast path: base biased back by W+1 pixels (never dereferenced below the allocation: those lanes are padding)
+  const long long pix_first = (long long)step_begin * W2_MS - p.win - 1;
+  const char* a_ptr = static_cast<const char*>(p.a0) + pix_first * p.c0 * 2;
+  long long a_left = (total_pix - pix_first) * p.c0 * 2;
+  const __amdgpu_buffer_rsrc_t rs_a_general = rsrc(p.a0, bytes_a0);
+  int st_row0 = step_begin * W2_MS;                        // first output row of the step being staged
+  auto clamp31 = [](long long b) {                         // num_records of a descriptor, from 32-bit scalar compares
+    const int hi = (int)(b >> 32);
+    const unsigned lo = (unsigned)b;
+    return hi < 0 ? 0 : (hi > 0 || lo > 0x7fffffffu) ? 0x7fffffff : (int)lo;
+  };
+
+  auto stage = [&](int slot, int /*step: consecutive from step_begin*/) {
     unsigned char* s0 = smem + slot * SLOT;
-    const long long row0 = (long long)step * W2_MS;       // uniform
-    const __amdgpu_buffer_rsrc_t rs_dy = rsrc(static_cast<const char*>(p.dy) + row0 * p.N * 2, (p.M - row0) * (long long)p.N * 2);
-    // fast path: base biased back by W+1 pixels (never dereferenced below the allocation: those lanes are padding)
-    const long long pix0 = row0 - p.win - 1;
-    const __amdgpu_buffer_rsrc_t rs_a0 = fast ? rsrc(static_cast<const char*>(p.a0) + pix0 * p.c0 * 2, (total_pix - pix0) * p.c0 * 2)
-                                              : rsrc(p.a0, bytes_a0);
-    const __amdgpu_buffer_rsrc_t rs_a1 = !TWO_SRC ? rs_a0
-                                         : fast ? rsrc(static_cast<const char*>(p.a1) + pix0 * p.c1 * 2, (total_pix - pix0) * p.c1 * 2)
-                                                : rsrc(p.a1, bytes_a1);
-#pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      const int q = j * 8 + wave;
-      if (q >= NI) break;
-      if (q < NI0) {
-        dma(rs_dy, s0 + q * 1024, s_col[j]);
-        continue;
-      }
-      unsigned char* dst = s0 + IMG0 + (q - NI0) * 1024;
-      const int kh = s_tap[j] & 3, kw = (s_tap[j] >> 2) & 3;
-      const bool second = TWO_SRC && (s_tap[j] & 16);
-      unsigned vo;
-      if (fast && p.ksize == 1) {
-        vo = s_col[j];
-      } else {
-        int oh, ow, b = 0;
-        if (pow2) {
-          const int m = (int)row0 + s_row[j];
-          ow = m & (p.wout - 1);
-          oh = (m >> wlog) & (p.hout - 1);
-          if (!fast) b = m >> (wlog + (31 - __builtin_clz(p.hout)));
-        } else {    // exact float reciprocals: the operands are far below 2^20
-          const int pw = g_ow + s_row[j];
-          const int qw = (int)(((float)pw + 0.5f) * inv_w);
-          ow = pw - qw * p.wout;
-          const int ph = g_oh + qw;
-          const int qh = (int)(((float)ph + 0.5f) * inv_h);
-          oh = ph - qh * p.hout;
-          b = g_b + qh;
+    const int row0 = st_row0;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dy_ptr), 0, clamp31(dy_left), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a0 =
+        FAST ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a_ptr), 0, clamp31(a_left), 0x00020000) : rs_a_general;
+    [&]<int... J>(std::integer_sequence<int, J...>) {
+      ([&] {
+        constexpr int j = J;
+        const int q = j * 8 + wave;
+        bool live = true;
+        if constexpr ((j + 1) * 8 > NI) live = q < NI;                       // only the last pass can run past the images
+        bool is_dy;
+        if constexpr ((j + 1) * 8 <= NI0) is_dy = true;                      // whole pass inside the dY image
+        else if constexpr (j * 8 >= NI0) is_dy = false;                      // whole pass inside the A image
+        else is_dy = q < NI0;                                                // straddling pass: wave-uniform branch
+        if (live && is_dy) {
+          dma(rs_dy, s0 + q * 1024, s_col[j]);
+        } else if (live) {
+          unsigned char* dst = s0 + IMG0 + (q - NI0) * 1024;
+          const int kh = s_tap[j] & 3, kw = (s_tap[j] >> 2) & 3;
+          unsigned vo;
+          if constexpr (ONE_TAP) {
+            vo = s_col[j];
+          } else {
+            int oh, ow, b = 0;
+            if (pow2) {
+              const int m = row0 + s_row[j];
+              ow = m & (p.wout - 1);
+              oh = (m >> wlog) & (p.hout - 1);
+              if (!fast) b = m >> (wlog + (31 - __builtin_clz(p.hout)));
+            } else {    // exact float reciprocals: the operands are far below 2^20
+              const int pw = g_ow + s_row[j];
+              const int qw = (int)(((float)pw + 0.5f) * inv_w);
+              ow = pw - qw * p.wout;
+              const int ph = g_oh + qw;
+              const int qh = (int)(((float)ph + 0.5f) * inv_h);
+              oh = ph - qh * p.hout;
+              b = g_b + qh;
+            }
+            if (fast) {
+              const bool ok = (unsigned)(oh + kh - pad) < (unsigned)p.hin && (unsigned)(ow + kw - pad) < (unsigned)p.win;
+              vo = ok ? s_col[j] : OOB;
+            } else {
+              const unsigned m = (unsigned)row0 + s_row[j];
+              int ih = oh * p.stride - pad + kh, iw = ow * p.stride - pad + kw;
+              const bool ok = s_col[j] != OOB && m < (unsigned)p.M && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
+              if (p.upsample) { ih >>= 1; iw >>= 1; }
+              vo = ok ? (unsigned)((b * p.hin + ih) * p.win + iw) * (unsigned)p.c0 * 2u + s_col[j] : OOB;
+            }
+          }
+          dma(rs_a0, dst, vo);
         }
-        if (fast) {
-          const bool ok = (unsigned)(oh + kh - pad) < (unsigned)p.hin && (unsigned)(ow + kw - pad) < (unsigned)p.win;
-          vo = ok ? s_col[j] : OOB;
-        } else {
-          const unsigned m = (unsigned)row0 + s_row[j];
-          int ih = oh * p.stride - pad + kh, iw = ow * p.stride - pad + kw;
-          const bool ok = s_col[j] != OOB && m < (unsigned)p.M && ih >= 0 && ih < hlim && iw >= 0 && iw < wlim;
-          if (p.upsample) { ih >>= 1; iw >>= 1; }
-          const int cs = second ? p.c1 : p.c0;
-          vo = ok ? (unsigned)((b * p.hin + ih) * p.win + iw) * (unsigned)cs * 2u + s_col[j] : OOB;
-        }
-      }
-      if (second) dma(rs_a1, dst, vo);
-      else dma(rs_a0, dst, vo);
-    }
+      }(), ...);
+    }(std::make_integer_sequence<int, JMAX>{});
+    dy_ptr += dy_step; dy_left -= dy_step;
+    if constexpr (FAST) { a_ptr += a_step; a_left -= a_step; }
+    st_row0 += W2_MS;
     if constexpr (!FAST) {
       g_ow += d_ow;
       if (g_ow >= p.wout) { g_ow -= p.wout; g_oh += 1; }
@@ -432,35 +456,64 @@ conv_wgrad_bf16_v2_kernel(const WgradParams p) {
       asm volatile("" ::: "memory");
       const unsigned sbase = lds_base + slot * SLOT;
       bf16x4_t lo0[F0], hi0[F0], lo1[F1], hi1[F1];
-#pragma unroll
-      for (int i = 0; i < F0; ++i) {
+      // Fragment reads in the order the MFMAs need them -- the shorter list (needed by every group) first, then the longer
+      // one group by group -- and counted waits: group g starts as soon as ITS reads are back (lgkmcnt counts in issue
+      // order), while the reads of the later groups are still in flight.  One wait for everything left the matrix cores
+      // idle for the ~400 cycles the CU's LDS needs to serve 8 waves x 24 transposed reads after each barrier.
+      constexpr bool OUT0 = F0 >= F1;                      // outer loop over the longer fragment list
+      constexpr int NOUT = OUT0 ? F0 : F1;
+      auto read0 = [&](int i) {
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo0[i]) : "v"(sbase + off0[i]) : "memory");
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi0[i]) : "v"(sbase + off0[i]), "n"(16 * T0 * 2) : "memory");
-      }
-#pragma unroll
-      for (int j = 0; j < F1; ++j) {
+      };
+      auto read1 = [&](int j) {
         asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo1[j]) : "v"(sbase + off1[j]) : "memory");
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi1[j]) : "v"(sbase + off1[j]), "n"(16 * T1 * 2) : "memory");
+      };
+      if constexpr (OUT0) {
+#pragma unroll
+        for (int j = 0; j < F1; ++j) read1(j);
+#pragma unroll
+        for (int i = 0; i < F0; ++i) read0(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < F0; ++i) read0(i);
+#pragma unroll
+        for (int j = 0; j < F1; ++j) read1(j);
       }
       if (s + 2 < nsteps) stage(slot == 0 ? 2 : slot - 1, step_begin + s + 2);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      // tie every fragment to a point behind the wait (volatile asm keeps its order), so no MFMA can be moved above it
-#pragma unroll
-      for (int i = 0; i < F0; ++i) asm volatile("" : "+v"(lo0[i]), "+v"(hi0[i]));
-#pragma unroll
-      for (int j = 0; j < F1; ++j) asm volatile("" : "+v"(lo1[j]), "+v"(hi1[j]));
       bf16x8_t f0[F0], f1[F1];
+      auto join = [](const bf16x4_t& lo, const bf16x4_t& hi) {
+        return bf16x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      };
+      [&]<int... G>(std::integer_sequence<int, G...>) {
+        ([&] {
+          // all but the reads of the groups after G have returned (scalar loads in between only make the wait stricter)
+          constexpr int LEFT = 2 * (NOUT - 1 - G);         // the counter saturates at 15: a smaller bound only waits longer
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LEFT < 15 ? LEFT : 15) : "memory");
+          // tie the fragments to a point behind the wait (volatile asm keeps its order): no MFMA on them moves above it
+          if constexpr (OUT0) {
+            if constexpr (G == 0) {
 #pragma unroll
-      for (int i = 0; i < F0; ++i) f0[i] = bf16x8_t{lo0[i][0], lo0[i][1], lo0[i][2], lo0[i][3], hi0[i][0], hi0[i][1], hi0[i][2], hi0[i][3]};
+              for (int j = 0; j < F1; ++j) { asm volatile("" : "+v"(lo1[j]), "+v"(hi1[j])); f1[j] = join(lo1[j], hi1[j]); }
+            }
+            asm volatile("" : "+v"(lo0[G]), "+v"(hi0[G]));
+            f0[G] = join(lo0[G], hi0[G]);
 #pragma unroll
-      for (int j = 0; j < F1; ++j) f1[j] = bf16x8_t{lo1[j][0], lo1[j][1], lo1[j][2], lo1[j][3], hi1[j][0], hi1[j][1], hi1[j][2], hi1[j][3]};
-      // the MFMAs must not be scheduled above the wait
-      __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < F1; ++j) acc[G][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[G], f1[j], acc[G][j], 0, 0, 0);
+          } else {
+            if constexpr (G == 0) {
 #pragma unroll
-      for (int i = 0; i < F0; ++i)
+              for (int i = 0; i < F0; ++i) { asm volatile("" : "+v"(lo0[i]), "+v"(hi0[i])); f0[i] = join(lo0[i], hi0[i]); }
+            }
+            asm volatile("" : "+v"(lo1[G]), "+v"(hi1[G]));
+            f1[G] = join(lo1[G], hi1[G]);
 #pragma unroll
-        for (int j = 0; j < F1; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[i], f1[j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < F0; ++i) acc[i][G] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0[i], f1[G], acc[i][G], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }(), ...);
+      }(std::make_integer_sequence<int, NOUT>{});
       slot = slot == 2 ? 0 : slot + 1;
     }
   }
@@ -544,17 +597,17 @@ conv_wgrad_generic_kernel(const WgradParams p) {
   p.partial[(size_t)blockIdx.y * p.N * p.K + idx] = acc;
 }
 
-template <int T0, int T1, int W0, int W1, bool FAST>
+template <int T0, int T1, int W0, int W1, int MODE>
 static int launch_wgrad_v2(const WgradParams& p, dim3 grid, hipStream_t st) {
   constexpr int smem = 3 * W2_MS * (T0 + T1) * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, FAST>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, MODE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) { set_error("ldm_conv_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return LDM_EHIP; }
     attr_done = true;
   }
-  hipLaunchKernelGGL((conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, FAST>), grid, dim3(512), smem, st, p);
+  hipLaunchKernelGGL((conv_wgrad_bf16_v2_kernel<T0, T1, W0, W1, MODE>), grid, dim3(512), smem, st, p);
   return LDM_OK;
 }
 
@@ -703,11 +756,15 @@ static int wgrad_run(const LdmConvGemm* d, const void* dy, float* dw, int accumu
       int rc = LDM_OK;
       const bool pow2 = (d->wout & (d->wout - 1)) == 0 && (d->hout & (d->hout - 1)) == 0;
       const bool fastk = d->stride == 1 && !d->upsample && (d->ksize == 1 || pow2);
-      switch (p.cfg * 2 + (fastk ? 1 : 0)) {
-        case 2: rc = launch_wgrad_v2<256, 256, 2, 4, false>(p, grid, st); break;
-        case 3: rc = launch_wgrad_v2<256, 256, 2, 4, true>(p, grid, st); break;
-        case 5: rc = launch_wgrad_v2<320, 256, 2, 4, true>(p, grid, st); break;
-        case 7: rc = launch_wgrad_v2<256, 320, 4, 2, true>(p, grid, st); break;
+      const int mode = !fastk ? 0 : d->ksize == 1 ? 2 : 1;
+      switch (p.cfg * 4 + mode) {
+        case 4: rc = launch_wgrad_v2<256, 256, 2, 4, 0>(p, grid, st); break;
+        case 5: rc = launch_wgrad_v2<256, 256, 2, 4, 1>(p, grid, st); break;
+        case 6: rc = launch_wgrad_v2<256, 256, 2, 4, 2>(p, grid, st); break;
+        case 9: rc = launch_wgrad_v2<320, 256, 2, 4, 1>(p, grid, st); break;
+        case 10: rc = launch_wgrad_v2<320, 256, 2, 4, 2>(p, grid, st); break;
+        case 13: rc = launch_wgrad_v2<256, 320, 4, 2, 1>(p, grid, st); break;
+        case 14: rc = launch_wgrad_v2<256, 320, 4, 2, 2>(p, grid, st); break;
         default: set_error("ldm_conv_wgrad: internal: tile %d without the fast path", p.cfg); return LDM_EINVAL;
       }
       if (rc) return rc;
