@@ -92,13 +92,21 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if os.environ.get("LDM_BENCH_SHARE_GPU") == "1":   # rehearsal only: every rank on device 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl" on ROCm) is the backend of record; LDM_BENCH_BACKEND=gloo with LDM_BENCH_SHARE_GPU=1 only
+        # rehearses the launch contract with several ranks on a one-GPU box (RCCL refuses two ranks on one device).
+        backend = os.environ.get("LDM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ldm import ops
     from ldm.scheduling_ddpm import DDPMScheduler
@@ -151,7 +159,7 @@ def main():
     assert torch.isfinite(lat).all(), "non-finite latents"
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax)
 

@@ -199,6 +199,13 @@ int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c1, int dtyp
                         int groups, const float* stats, const float* gamma, const float* beta, int silu,
                         void* out, void* stream);
 
+/* nn.GroupNorm (+ nn.SiLU) in one call (unet.py:699-700, :705-706, :480, :113-114): statistics, normalisation and the
+ * (B, groups, 2) mean/rstd tensor the backward reads.  Feature maps whose (sample, group set) slice fits one workgroup
+ * (bf16, the 32x32 / 16x16 / 8x8 levels) run as ONE kernel: one read and one write per element; larger ones run
+ * ldm_groupnorm_stats + ldm_groupnorm_apply.  `workspace` as for ldm_groupnorm_stats. */
+int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups, float eps,
+                  const float* gamma, const float* beta, int silu, void* out, float* stats, float* workspace, void* stream);
+
 /* Row-wise LayerNorm over the last dimension (unet.py:550-551, :576), eps 1e-5. */
 int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,
                   const float* beta, void* out, void* stream);

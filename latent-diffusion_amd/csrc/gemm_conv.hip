@@ -130,6 +130,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int cpos = tid % CH;                 // chunk position inside the LDS row this thread fills
   int a_pix[A_IT], a_ih[A_IT], a_iw[A_IT], a_sw[A_IT];
   const int hw_out = p.hout * p.wout;
+  // pixel -> (sample, row, column): shifts when the output extents are powers of two (every level of a 64x64 or 32x32
+  // latent), and none at all for a pointwise stride-1 layer, whose input pixel IS the output row (block-uniform tests;
+  // the general path costs eight ~40-instruction integer divisions per thread before the first load is issued)
+  const bool ext_pow2 = ((hw_out & (hw_out - 1)) | (p.wout & (p.wout - 1))) == 0;
+  const int sh_hw = __builtin_ctz(hw_out), sh_w = __builtin_ctz(p.wout);
+  const bool pointwise = p.ksize == 1 && p.stride == 1 && !p.upsample;
+  auto sample_of = [&](int m) { return ext_pow2 ? m >> sh_hw : m / hw_out; };
   const int hlim = p.upsample ? p.hin * 2 : p.hin;
   const int wlim = p.upsample ? p.win * 2 : p.win;
   const int pad = p.ksize >> 1;
@@ -138,9 +145,12 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     const int r = (it * NT + tid) / CH;
     const int m = m0 + r;
     a_sw[it] = (cpos ^ swz<CH>(r)) * 8;      // source element offset inside the K-tile
-    if (m < p.M) {
-      const int b = m / hw_out, rem = m - b * hw_out;
-      const int oh = rem / p.wout, ow = rem - oh * p.wout;
+    if (m < p.M && pointwise) {
+      a_pix[it] = m;
+      a_ih[it] = a_iw[it] = 0;
+    } else if (m < p.M) {
+      const int b = sample_of(m), rem = m - b * hw_out;
+      const int oh = ext_pow2 ? rem >> sh_w : rem / p.wout, ow = rem - oh * p.wout;
       a_pix[it] = b * p.hin * p.win;
       a_ih[it] = oh * p.stride - pad;
       a_iw[it] = ow * p.stride - pad;
@@ -400,7 +410,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           qrow[ps] = make_uint4(0, 0, 0, 0);
           if (cok[ps] && m < p.M) {
             if (has_res) qres[ps] = *reinterpret_cast<const uint4*>(resid + (size_t)m * p.N + ncol[ps]);
-            if (has_row) qrow[ps] = *reinterpret_cast<const uint4*>(rowv + (size_t)(m / hw_out) * p.rowvec_stride + ncol[ps]);
+            if (has_row) qrow[ps] = *reinterpret_cast<const uint4*>(rowv + (size_t)sample_of(m) * p.rowvec_stride + ncol[ps]);
           }
         }
       };

@@ -245,6 +245,156 @@ static int gn_geom(int c0, int c1, int hw, int groups, int batch, GnGeom& g, int
   return LDM_OK;
 }
 
+// ------------------------------------------------------------------------------------- one-kernel GroupNorm
+// Small feature maps (the 32x32, 16x16 and 8x8 levels of the UNet): the slice of one (sample, set of GS adjacent groups)
+// fits the registers of one workgroup, so statistics and normalisation are ONE pass over HBM (2 B read + 2 B written per
+// element instead of two reads and a write) and ONE launch instead of three -- at these sizes the three-kernel form is
+// bound by launch boundaries, not bandwidth (35 us for 42 MB at 16x16).  GS is the smallest group count whose channels
+// fill whole 8-channel chunks.  A thread keeps one chunk column and up to GNF_MAXC pixels of it; per-channel partial sums
+// meet in LDS and one wave per group folds them in double in a fixed order (deterministic).
+constexpr int GNF_MAXC = 16;
+
+struct GnFusedGeom {
+  int c0, c1, ctot, cpg, groups, hw;
+  int gs;        // groups per workgroup
+  int cpr;       // 8-channel chunks per pixel of the workgroup's channel range
+  int pix;       // pixels per pass = blockDim / cpr
+  int iters;     // passes = ceil(hw / pix) <= GNF_MAXC
+};
+
+template <int NT>
+__global__ void __launch_bounds__(NT)
+gn_fused_kernel(const bf16_t* __restrict__ a0, const bf16_t* __restrict__ a1, GnFusedGeom g, float eps,
+                const float* __restrict__ gamma, const float* __restrict__ beta, int silu, bf16_t* __restrict__ out,
+                float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);          // [pix][seg][2]
+  __shared__ float gstat[4][2];
+  __shared__ double gpart[4][16][2];
+  const int b = blockIdx.y, set = blockIdx.x;
+  const int seg = g.gs * g.cpg;                              // channels of this workgroup
+  const int cbase = set * seg;
+  const int tid = threadIdx.x;
+  const int tp = tid / g.cpr, tc = tid - tp * g.cpr;
+  const bool active = tp < g.pix;
+  const int c = cbase + tc * 8;                              // first channel of this thread's chunk column
+  const bf16_t* src;
+  int cs;
+  if (c < g.c0) { src = a0 + c; cs = g.c0; } else { src = a1 + (c - g.c0); cs = g.c1; }
+  src += (size_t)b * g.hw * cs;
+
+  uint4 raw[GNF_MAXC];
+  float s[8], ss[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNF_MAXC; ++k) {
+    if (k < g.iters) {
+      const int p = k * g.pix + tp;
+      raw[k] = (active && p < g.hw) ? *reinterpret_cast<const uint4*>(src + (size_t)p * cs) : make_uint4(0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GNF_MAXC; ++k) {
+    if (k < g.iters) {
+      float v[8];
+      unpack8(raw[k], v);                                    // pixels past hw hold zeros: they add nothing
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+    }
+  }
+  if (active) {
+    float* r = red + ((size_t)tp * seg + tc * 8) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { r[2 * j] = s[j]; r[2 * j + 1] = ss[j]; }
+  }
+  __syncthreads();
+  // fold in double, fixed order: the waves share the groups (wpg waves per group, each a strided set of pixel rows, a
+  // lane a strided set of the group's channels), partial sums meet in LDS, one thread per group adds them in wave order
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wpg = (NT / 64) / g.gs;                          // >= 1 (checked on the host)
+  const int fgrp = wave / wpg, part = wave - fgrp * wpg;
+  if (fgrp < g.gs) {
+    double a = 0.0, q = 0.0;
+    for (int r = part; r < g.pix; r += wpg)
+      for (int ch = lane; ch < g.cpg; ch += 64) {
+        const float* e = red + ((size_t)r * seg + fgrp * g.cpg + ch) * 2;
+        a += (double)e[0];
+        q += (double)e[1];
+      }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      q += __shfl_xor(q, o, 64);
+    }
+    if (lane == 0) { gpart[fgrp][part][0] = a; gpart[fgrp][part][1] = q; }
+  }
+  __syncthreads();
+  if (tid < g.gs) {
+    double a = 0.0, q = 0.0;
+    for (int w = 0; w < wpg; ++w) { a += gpart[tid][w][0]; q += gpart[tid][w][1]; }
+    const double count = (double)g.hw * g.cpg;
+    const double mean = a / count;
+    double var = q / count - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float m = (float)mean, rs = (float)(1.0 / sqrt(var + (double)eps));
+    gstat[tid][0] = m;
+    gstat[tid][1] = rs;
+    float* o = stats + ((size_t)b * g.groups + set * g.gs + tid) * 2;
+    o[0] = m;
+    o[1] = rs;
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int grp = (tc * 8 + j) / g.cpg;
+    const float w = gstat[grp][1] * gamma[c + j];
+    sc[j] = w;
+    sh[j] = beta[c + j] - gstat[grp][0] * w;
+  }
+  bf16_t* dst = out + (size_t)b * g.hw * g.ctot + c;
+#pragma unroll
+  for (int k = 0; k < GNF_MAXC; ++k) {
+    if (k < g.iters) {
+      const int p = k * g.pix + tp;
+      if (p < g.hw) {
+        float v[8];
+        unpack8(raw[k], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float y = v[j] * sc[j] + sh[j];
+          if (silu) y = silu_fast(y);
+          v[j] = y;
+        }
+        store8(dst + (size_t)p * g.ctot, v);
+      }
+    }
+  }
+}
+
+// Geometry of the one-kernel form; false when the slice of a group set does not fit one workgroup.
+static bool gn_fused_geom(int c0, int c1, int hw, int groups, GnFusedGeom& g, int& threads, size_t& smem) {
+  const int ctot = c0 + c1;
+  if (c0 % 8 || c1 % 8 || groups < 1 || ctot % groups) return false;
+  g.c0 = c0; g.c1 = c1; g.ctot = ctot; g.groups = groups; g.hw = hw;
+  g.cpg = ctot / groups;
+  int gs = 1;
+  while (gs <= 4 && (gs * g.cpg) % 8) gs *= 2;
+  if (gs > 4 || groups % gs) return false;
+  g.gs = gs;
+  g.cpr = gs * g.cpg / 8;
+  for (int nt : {256, 512, 1024}) {
+    if (g.cpr > nt) continue;
+    g.pix = nt / g.cpr;
+    g.iters = (hw + g.pix - 1) / g.pix;
+    smem = (size_t)g.pix * gs * g.cpg * 2 * sizeof(float);
+    if (g.iters <= GNF_MAXC && smem <= 64 * 1024 && nt / 64 >= gs) { threads = nt; return true; }
+  }
+  return false;
+}
+
 // ------------------------------------------------------------------------------------- LayerNorm
 constexpr int LN_MAX_CHUNKS = 8;  // per lane -> cols <= 4096
 // One wave normalises ROWS rows at a time, a lane holding CPL 8-element chunks of each: all ROWS*CPL loads are in
@@ -386,6 +536,33 @@ extern "C" int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c
                        gamma, beta, silu, (float*)out);
   LDM_HIP_CHECK_LAUNCH("ldm_groupnorm_apply");
   return LDM_OK;
+}
+
+extern "C" int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups,
+                             float eps, const float* gamma, const float* beta, int silu, void* out, float* stats,
+                             float* workspace, void* stream) {
+  LDM_REQUIRE(dtype_ok(dtype), "ldm_groupnorm: bad dtype %d", dtype);
+  LDM_REQUIRE(batch >= 0 && hw >= 1, "ldm_groupnorm: bad sizes");
+  if (batch == 0) return LDM_OK;
+  GnFusedGeom g;
+  int threads = 0;
+  size_t smem = 0;
+  if (dtype == LDM_BF16 && batch <= 65535 && gn_fused_geom(c0, c1, hw, groups, g, threads, smem)) {
+    LDM_REQUIRE(a0 && stats && gamma && beta && out && (c1 == 0 || a1), "ldm_groupnorm: null pointer");
+    LDM_REQUIRE(aligned16(a0) && aligned16(out) && (c1 == 0 || aligned16(a1)), "ldm_groupnorm: buffers must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(groups / g.gs, batch);
+#define LDM_GN_FUSED(NT) \
+  hipLaunchKernelGGL((gn_fused_kernel<NT>), grid, dim3(NT), smem, st, (const bf16_t*)a0, (const bf16_t*)a1, g, eps, gamma, beta, \
+                     silu, (bf16_t*)out, stats)
+    if (threads == 256) LDM_GN_FUSED(256); else if (threads == 512) LDM_GN_FUSED(512); else LDM_GN_FUSED(1024);
+#undef LDM_GN_FUSED
+    LDM_HIP_CHECK_LAUNCH("ldm_groupnorm(one kernel)");
+    return LDM_OK;
+  }
+  const int rc = ldm_groupnorm_stats(a0, a1, c0, c1, dtype, batch, hw, groups, eps, stats, workspace, stream);
+  if (rc) return rc;
+  return ldm_groupnorm_apply(a0, a1, c0, c1, dtype, batch, hw, groups, stats, gamma, beta, silu, out, stream);
 }
 
 extern "C" int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,

@@ -292,10 +292,11 @@ _gn_ws = {}
 
 def _gn_workspace(device, batch: int, groups: int) -> torch.Tensor:
     need = _lib.load().ldm_groupnorm_workspace_floats(batch, groups)
-    ws = _gn_ws.get(device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)   # per stream: micro-batches run concurrently
+    ws = _gn_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.float32, device=device)
-        _gn_ws[device] = ws
+        _gn_ws[key] = ws
     return ws
 
 
@@ -314,11 +315,9 @@ def groupnorm(a0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups:
     with torch.cuda.device(a0.device):
         st = _stream(a0)
         ws = _gn_workspace(a0.device, B, groups)
-        _lib.check(lib.ldm_groupnorm_stats(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, stats.data_ptr(),
-                                           ws.data_ptr(), st), "ldm_groupnorm_stats")
-        _lib.check(lib.ldm_groupnorm_apply(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, stats.data_ptr(),
-                                           gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, out.data_ptr(), st),
-                   "ldm_groupnorm_apply")
+        _lib.check(lib.ldm_groupnorm(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, gamma.data_ptr(),
+                                     beta.data_ptr(), 1 if silu else 0, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), st),
+                   "ldm_groupnorm")
     return out
 
 
@@ -336,11 +335,9 @@ def groupnorm_with_stats(a0, gamma, beta, groups, *, a1=None, silu=False, eps=1e
     with torch.cuda.device(a0.device):
         st = _stream(a0)
         ws = _gn_workspace(a0.device, B, groups)
-        _lib.check(lib.ldm_groupnorm_stats(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, stats.data_ptr(),
-                                           ws.data_ptr(), st), "ldm_groupnorm_stats")
-        _lib.check(lib.ldm_groupnorm_apply(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, stats.data_ptr(),
-                                           gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, out.data_ptr(), st),
-                   "ldm_groupnorm_apply")
+        _lib.check(lib.ldm_groupnorm(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, gamma.data_ptr(),
+                                     beta.data_ptr(), 1 if silu else 0, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), st),
+                   "ldm_groupnorm")
     return out, stats
 
 

@@ -461,6 +461,30 @@ def test_groupnorm_concat_straddle(dtype, c0, c1):
     assert rel_l2(y, ref) < TOL[dtype]
 
 
+@pytest.mark.parametrize("B,c0,c1,H,W", [(2, 640, 0, 32, 32), (2, 1280, 640, 32, 32), (2, 640, 320, 32, 32), (3, 1280, 0, 16, 16),
+                                          (2, 1280, 1280, 16, 16), (2, 1280, 1280, 8, 8), (1, 320, 0, 24, 24), (2, 96, 32, 7, 9),
+                                          (2, 320, 0, 64, 64)])
+def test_groupnorm_one_kernel_shapes(B, c0, c1, H, W):
+    """ldm_groupnorm on the UNet's bf16 shapes below 64x64 (one workgroup per (sample, group set): 256, 512 and 1024
+    threads, up to 16 pixels per thread, groups that straddle a chunk or the concat boundary) and one 64x64 shape that
+    stays on the three-kernel path: output against F.group_norm + SiLU on the same bf16-rounded input, and the
+    mean / rstd tensor (what the backward reads) against float64 statistics of that input."""
+    ops = _ops()
+    C = c0 + c1
+    a, ar = _q(seeded((B, H, W, c0), 11) * 1.3 + 0.4, torch.bfloat16)
+    s, sr = (_q(seeded((B, H, W, c1), 12) * 2.0 - 0.5, torch.bfloat16) if c1 else (None, None))
+    g, be = 1 + 0.1 * seeded((C,), 13), 0.1 * seeded((C,), 14)
+    y, stats = ops.groupnorm_with_stats(a, g.cuda(), be.cuda(), 32, a1=s, silu=True)
+    xr = ar if c1 == 0 else torch.cat([ar, sr], dim=-1)
+    ref = nhwc(F.silu(F.group_norm(xr.permute(0, 3, 1, 2), 32, g, be, 1e-5)))
+    assert y.shape == (B, H, W, C) and rel_l2(y, ref) < TOL[torch.bfloat16]
+    x64 = xr.double().reshape(B, H * W, 32, C // 32)
+    mean = x64.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(x64.var(dim=(1, 3), unbiased=False) + 1e-5)
+    assert torch.allclose(stats[..., 0].cpu().double(), mean, rtol=0, atol=2e-6 * float(x64.abs().max()))
+    assert torch.allclose(stats[..., 1].cpu().double(), rstd, rtol=1e-5, atol=0)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rows,C", [(1000, 320), (77, 640), (5, 1280), (4096, 32), (3, 64)])
 def test_layernorm(dtype, rows, C):
