@@ -252,7 +252,8 @@ static int gn_geom(int c0, int c1, int hw, int groups, int batch, GnGeom& g, int
 // bound by launch boundaries, not bandwidth (35 us for 42 MB at 16x16).  GS is the smallest group count whose channels
 // fill whole 8-channel chunks.  A thread keeps one chunk column and up to GNF_MAXC pixels of it; per-channel partial sums
 // meet in LDS and one wave per group folds them in double in a fixed order (deterministic).
-constexpr int GNF_MAXC = 16;
+constexpr int GNF_MAXC = 16;        // pixels per thread of the common instantiations
+constexpr int GNF_MAXC_BIG = 21;    // 64x64 x 40 channels (C = 320 / 640 at the top level): 320 KB in 1024 threads' registers
 
 struct GnFusedGeom {
   int c0, c1, ctot, cpg, groups, hw;
@@ -262,7 +263,7 @@ struct GnFusedGeom {
   int iters;     // passes = ceil(hw / pix) <= GNF_MAXC
 };
 
-template <int NT>
+template <int NT, int MAXC>
 __global__ void __launch_bounds__(NT)
 gn_fused_kernel(const bf16_t* __restrict__ a0, const bf16_t* __restrict__ a1, GnFusedGeom g, float eps,
                 const float* __restrict__ gamma, const float* __restrict__ beta, int silu, bf16_t* __restrict__ out,
@@ -283,19 +284,19 @@ gn_fused_kernel(const bf16_t* __restrict__ a0, const bf16_t* __restrict__ a1, Gn
   if (c < g.c0) { src = a0 + c; cs = g.c0; } else { src = a1 + (c - g.c0); cs = g.c1; }
   src += (size_t)b * g.hw * cs;
 
-  uint4 raw[GNF_MAXC];
+  uint4 raw[MAXC];
   float s[8], ss[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
 #pragma unroll
-  for (int k = 0; k < GNF_MAXC; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     if (k < g.iters) {
       const int p = k * g.pix + tp;
       raw[k] = (active && p < g.hw) ? *reinterpret_cast<const uint4*>(src + (size_t)p * cs) : make_uint4(0, 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int k = 0; k < GNF_MAXC; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     if (k < g.iters) {
       float v[8];
       unpack8(raw[k], v);                                    // pixels past hw hold zeros: they add nothing
@@ -356,7 +357,7 @@ gn_fused_kernel(const bf16_t* __restrict__ a0, const bf16_t* __restrict__ a1, Gn
   }
   bf16_t* dst = out + (size_t)b * g.hw * g.ctot + c;
 #pragma unroll
-  for (int k = 0; k < GNF_MAXC; ++k) {
+  for (int k = 0; k < MAXC; ++k) {
     if (k < g.iters) {
       const int p = k * g.pix + tp;
       if (p < g.hw) {
@@ -390,7 +391,7 @@ static bool gn_fused_geom(int c0, int c1, int hw, int groups, GnFusedGeom& g, in
     g.pix = nt / g.cpr;
     g.iters = (hw + g.pix - 1) / g.pix;
     smem = (size_t)g.pix * gs * g.cpg * 2 * sizeof(float);
-    if (g.iters <= GNF_MAXC && smem <= 64 * 1024 && nt / 64 >= gs) { threads = nt; return true; }
+    if (g.iters <= (nt == 1024 ? GNF_MAXC_BIG : GNF_MAXC) && smem <= 64 * 1024 && nt / 64 >= gs) { threads = nt; return true; }
   }
   return false;
 }
@@ -552,10 +553,13 @@ extern "C" int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int
     LDM_REQUIRE(aligned16(a0) && aligned16(out) && (c1 == 0 || aligned16(a1)), "ldm_groupnorm: buffers must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(groups / g.gs, batch);
-#define LDM_GN_FUSED(NT) \
-  hipLaunchKernelGGL((gn_fused_kernel<NT>), grid, dim3(NT), smem, st, (const bf16_t*)a0, (const bf16_t*)a1, g, eps, gamma, beta, \
-                     silu, (bf16_t*)out, stats)
-    if (threads == 256) LDM_GN_FUSED(256); else if (threads == 512) LDM_GN_FUSED(512); else LDM_GN_FUSED(1024);
+#define LDM_GN_FUSED(NT, MAXC) \
+  hipLaunchKernelGGL((gn_fused_kernel<NT, MAXC>), grid, dim3(NT), smem, st, (const bf16_t*)a0, (const bf16_t*)a1, g, eps, gamma, \
+                     beta, silu, (bf16_t*)out, stats)
+    if (threads == 256) LDM_GN_FUSED(256, GNF_MAXC);
+    else if (threads == 512) LDM_GN_FUSED(512, GNF_MAXC);
+    else if (g.iters <= GNF_MAXC) LDM_GN_FUSED(1024, GNF_MAXC);
+    else LDM_GN_FUSED(1024, GNF_MAXC_BIG);
 #undef LDM_GN_FUSED
     LDM_HIP_CHECK_LAUNCH("ldm_groupnorm(one kernel)");
     return LDM_OK;

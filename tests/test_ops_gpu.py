@@ -463,11 +463,11 @@ def test_groupnorm_concat_straddle(dtype, c0, c1):
 
 @pytest.mark.parametrize("B,c0,c1,H,W", [(2, 640, 0, 32, 32), (2, 1280, 640, 32, 32), (2, 640, 320, 32, 32), (3, 1280, 0, 16, 16),
                                           (2, 1280, 1280, 16, 16), (2, 1280, 1280, 8, 8), (1, 320, 0, 24, 24), (2, 96, 32, 7, 9),
-                                          (2, 320, 0, 64, 64)])
+                                          (2, 320, 0, 64, 64), (1, 320, 320, 64, 64), (1, 640, 320, 64, 64)])
 def test_groupnorm_one_kernel_shapes(B, c0, c1, H, W):
-    """ldm_groupnorm on the UNet's bf16 shapes below 64x64 (one workgroup per (sample, group set): 256, 512 and 1024
-    threads, up to 16 pixels per thread, groups that straddle a chunk or the concat boundary) and one 64x64 shape that
-    stays on the three-kernel path: output against F.group_norm + SiLU on the same bf16-rounded input, and the
+    """ldm_groupnorm on the UNet's bf16 shapes (one workgroup per (sample, group set): 256, 512 and 1024 threads, up to
+    16 pixels per thread -- 21 for the 40-channel group sets of the 64x64 level --, groups that straddle a chunk or the
+    concat boundary) and the one 64x64 shape (960 = 640 + 320 channels) that stays on the three-kernel path: output against F.group_norm + SiLU on the same bf16-rounded input, and the
     mean / rstd tensor (what the backward reads) against float64 statistics of that input."""
     ops = _ops()
     C = c0 + c1
