@@ -127,7 +127,31 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
             for n, m in resnets:
                 P[n + ".time_off"] = off
                 off += m.out_channels
+        cross = [(n, m) for n, m in root.named_modules() if isinstance(m, Attention) and not m.fused_qkv]
+        if isinstance(root, UNet) and cross and not train:
+            # inference: the K|V projections of the text context of every cross-attention (unet.py:634, :656; 16 GEMMs
+            # with 2,464 rows each, none of which depends on the image path) as one filter; each layer reads its
+            # column slice of the (B, 77, sum 2C) result
+            pack_fused("ctx_kv_all", [m.kv_proj.weight for _, m in cross])
+            off = 0
+            for n, m in cross:
+                P[n + ".kv_off"] = off
+                off += m.kv_proj.weight.shape[0]
     return P
+
+
+class _ContextKV:
+    """The text context together with the K|V projections of all cross-attention layers (one GEMM, `ctx_kv_all`)."""
+
+    def __init__(self, P, ctx):
+        self.ctx = ctx
+        self.kv_all = ops.conv_gemm(ctx, P["ctx_kv_all.w"])
+
+    def of(self, P, name, width):
+        off = P.get(name + ".kv_off")
+        if off is None:      # a cross-attention as wide as the context keeps its own projection
+            return ops.conv_gemm(self.ctx, P[_j(name, "kv_proj.w")])
+        return self.kv_all[..., off:off + width]
 
 
 class _HipModule(nn.Module):
@@ -192,7 +216,10 @@ def run_attention(P, n: str, a: "Attention", x, ctx, residual=None):
         q, kv = qkv[..., :C], qkv[..., C:]
     else:
         q = ops.conv_gemm(x, P[_j(n, "q_proj.w")])
-        kv = ops.conv_gemm(x if ctx is None else ctx, P[_j(n, "kv_proj.w")])
+        if isinstance(ctx, _ContextKV):
+            kv = ctx.of(P, n, 2 * C)
+        else:
+            kv = ops.conv_gemm(x if ctx is None else ctx, P[_j(n, "kv_proj.w")])
     att = ops.attention(q, kv, a.num_heads)
     return ops.conv_gemm(att, P[_j(n, "output_proj.0.w")], bias=P[_j(n, "output_proj.0.b")], residual=residual)
 
@@ -546,6 +573,8 @@ class UNet(_HipModule):
             return run_resnet(P, name, r, x, skip, tproj[:, off:off + r.out_channels])
 
         ctx = encoder_hidden_states.to(dt).contiguous()
+        if "ctx_kv_all.w" in P:
+            ctx = _ContextKV(P, ctx)
         h = ops.conv_in(sample.contiguous(), P["conv_in.w"], P["conv_in.b"], dt)
         skips = [h]
         for i, blk in enumerate(self.down_blocks):
