@@ -328,3 +328,27 @@ def test_micro_batch_streams_match_single_stream():
         torch.cuda.synchronize()
         net.micro_batch_streams = 1
         assert rel_l2(a, net(x, t, ctx)) < 1e-6 and rel_l2(b, net(x + 1, t, ctx)) < 1e-6
+
+
+def test_empty_and_single_sample_batches():
+    """Edge sizes of the boundary: an EMPTY batch goes through the UNet, the scheduler's add_noise / step and the
+    sampler without a launch error and yields empty results of the right shape and dtype; batch 1 and batch 3 (the
+    sizes the reference's own smoke script tries, unet.py:858) agree with rows of a larger batch."""
+    from ldm.scheduling_ddpm import DDPMScheduler
+    net, _, _ = _small_unet()
+    sch = DDPMScheduler(device=torch.device("cuda"))
+    sch.set_timesteps(10)
+    x, ctx = seeded((3, 4, 16, 16), 51).cuda(), seeded((3, 77, 768), 52).cuda()
+    with torch.no_grad():
+        for dt in (torch.float32, torch.bfloat16):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dt == torch.bfloat16):
+                e0 = net(x[:0], 500, ctx[:0].to(dt))
+                assert e0.shape == (0, 4, 16, 16)
+                full = net(x, 500, ctx.to(dt))
+                one = net(x[1:2], 500, ctx[1:2].to(dt))
+            assert rel_l2(one, full[1:2]) < (1e-5 if dt == torch.float32 else 2e-2)
+        out = sch.step(e0.float(), 500, x[:0], noise=x[:0])
+        assert out.prev_sample.shape == (0, 4, 16, 16) and out.prev_sample.dtype == torch.float32
+        noisy = sch.add_noise(x[:0], x[:0], torch.zeros(0, dtype=torch.int64, device="cuda"))
+        assert noisy.shape == (0, 4, 16, 16)
+    torch.cuda.synchronize()
