@@ -188,6 +188,72 @@ conv_in_kernel(const TX* __restrict__ x, const float* __restrict__ w, const floa
   }
 }
 
+// conv_in, four horizontally adjacent pixels per thread: the 36 x 8 filter words a thread reads from LDS and the input
+// values of a row serve four outputs (the one-pixel form spends its time on LDS filter reads: 72 ds_read_b128 per pixel
+// and chunk against 288 FMAs).  Needs wd % 4 == 0; the input row segment [ow0 - 1, ow0 + 4] is read once per (ci, kh).
+template <typename TX, typename TO, int CIN>
+__global__ void __launch_bounds__(256)
+conv_in4_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
+                int batch, int h, int wd, int cout, int cblk) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [CIN*9][cb]
+  constexpr int TAPS = CIN * 9;
+  const int co0 = blockIdx.y * cblk;
+  const int cb = cout - co0 < cblk ? cout - co0 : cblk;
+  for (int i = threadIdx.x; i < TAPS * cb; i += 256) {
+    const int co = i / TAPS, tap = i - co * TAPS;   // w is [cout][CIN][3][3]
+    wl[tap * cb + co] = w[(size_t)co0 * TAPS + i];
+  }
+  __syncthreads();
+  const unsigned chunks = cb >> 3;
+  const unsigned wq = (unsigned)wd >> 2;                           // pixel quads per row
+  const unsigned total = (unsigned)batch * h * wq * chunks;        // < 2^31 (checked on the host)
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const unsigned quad = i / chunks;
+    const int ch = (int)(i - quad * chunks);
+    const unsigned prow = quad / wq;
+    const int ow0 = (int)(quad - prow * wq) * 4;
+    const int b = (int)(prow / (unsigned)h);
+    const int oh = (int)(prow - (unsigned)b * h);
+    float acc[4][8];
+    {
+      float bv[8];
+      load8(bias + co0 + ch * 8, bv);
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[q][j] = bv[j];
+    }
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
+        float v[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+          const int iw = ow0 + e - 1;
+          v[e] = 0.f;
+          if (ih >= 0 && ih < h && iw >= 0 && iw < wd) v[e] = Elem<TX>::ld(x + (((int64_t)b * CIN + ci) * h + ih) * wd + iw);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          float wv[8];
+          load8(wl + ((ci * 3 + kh) * 3 + kw) * cb + ch * 8, wv);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[q][j] += v[q + kw] * wv[j];
+        }
+      }
+    }
+    const size_t pix0 = (size_t)prow * wd + ow0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store8(out + (pix0 + q) * cout + co0 + ch * 8, acc[q]);
+  }
+}
+
 // generic channel count (slow path)
 template <typename TX, typename TO>
 __global__ void __launch_bounds__(256)
@@ -400,6 +466,14 @@ static int conv_in_dispatch(const void* x, const float* w, const float* bias, vo
   if (cin == 4 && cout % 8 == 0 && aligned16(out) && aligned16(bias) && npix * (cout / 8) < (1LL << 31)) {
     const int cblk = cout <= 448 ? cout : 256;   // output channels per workgroup: 36 * cblk floats of LDS (<= 64 KB)
     const int ny = (cout + cblk - 1) / cblk;
+    if (wd % 4 == 0 && npix >= 4096) {   // four pixels per thread (the summation order per output is the same)
+      int64_t nb = (npix / 4 * (cblk / 8) + 255) / 256;
+      if (nb > 2048) nb = 2048;
+      hipLaunchKernelGGL((conv_in4_kernel<TX, TO, 4>), dim3((int)nb, ny), dim3(256), (size_t)36 * cblk * sizeof(float), st,
+                         (const TX*)x, w, bias, (TO*)out, batch, h, wd, cout, cblk);
+      LDM_HIP_CHECK_LAUNCH("ldm_conv_in");
+      return LDM_OK;
+    }
     int64_t nb = (npix * (cblk / 8) + 255) / 256;
     if (nb > 2048) nb = 2048;  // grid-stride: the LDS filter image is filled once per block
     hipLaunchKernelGGL((conv_in_kernel<TX, TO, 4>), dim3((int)nb, ny), dim3(256), (size_t)36 * cblk * sizeof(float), st, (const TX*)x,
