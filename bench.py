@@ -179,7 +179,7 @@ def main():
         achieved = fl / tt
         # HBM bytes per launch of the dominant kernel: not measurable from inside the process; the figure is the one the
         # separate rocprofv3 --pmc passes over this same command gave (FETCH_SIZE, doubled per the gfx950 correction, +
-        # WRITE_SIZE; profiles/r1_v9_pmc_per_kernel.md), reported only for the shape it was measured on.
+        # WRITE_SIZE; profiles/r1_v10_pmc_per_kernel.md), reported only for the shape it was measured on.
         pmc_traffic = {"conv_gemm_bf16_kernel<256,160,64>": 288.2e6}
         traffic = pmc_traffic.get(dom) if (LAT == 64 and B == BATCH) else None
         out = {
@@ -198,7 +198,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": traffic,
                          "traffic_note": "HBM+Infinity-Cache bytes per launch from committed PMC passes "
-                                         "(profiles/r1_v9_pmc_per_kernel.md), not collected live",
+                                         "(profiles/r1_v10_pmc_per_kernel.md), not collected live",
                          "launches": n_l, "avg_launch_us": round(1e6 * tt / n_l, 1),
                          "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 2),
                          "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),

@@ -92,6 +92,16 @@ __device__ __forceinline__ uint4 buffer_load16(const void* base, unsigned bytes,
 // the running maximum is only raised (and O rescaled) when some query's maximum grew by more than 2^8, and for
 // d = 40 the denominator comes out of the PV product (AttnGeom::ONES).  One barrier per key tile: tile t+1 is
 // committed to the other LDS buffer while tile t is being consumed.
+// Maximum over the four 16-lane rows of a wave (the key quarters fq of one query column) on the vector ALU:
+// v_permlane16_swap / v_permlane32_swap exchange rows between two registers, so the butterfly needs no trip through the
+// LDS crossbar (ds_bpermute, ~100+ cycles of latency twice per query group and key tile, sat on the tile's critical path).
+__device__ __forceinline__ float max_over_fq(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <int D>
 __global__ void __launch_bounds__(256, (D <= 80 ? 2 : 1))
 attention_bf16_kernel(const AttnParams p) {
@@ -226,8 +236,7 @@ attention_bf16_kernel(const AttnParams p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[g][kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = max_over_fq(mx);
       float pv[4][4];
       if constexpr (G::AUG) {
         // s already is score*scale - m_run.  Lazy maximum: m_run is raised (and O rescaled) only when some query of
@@ -325,8 +334,10 @@ attention_bf16_kernel(const AttnParams p) {
     __syncthreads();   // tile t is in `cur` for every wave, and every wave is done reading `nxt` (tile t-1)
     if (t == 8) ATT_STAMP(3);
     if (t + 1 < ntiles) {
+      __builtin_amdgcn_s_setprio(3);      // the few staging instructions go ahead of the other waves' math
       commit(nxt);                        // tile t+1: its loads were issued a whole tile ago
       if (t + 2 < ntiles) fetch(t + 2);   // in flight under the math below
+      __builtin_amdgcn_s_setprio(0);
     }
     if (t == 8) ATT_STAMP(4);
     if (t + 1 == ntiles && (p.lk & 63) != 0) tile(std::true_type{}, cur, t * 64, t == 0);

@@ -18,7 +18,7 @@ def main():
         e[0] += 1
         e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
     # the last complete forward: between the last two conv_in launches
-    idx = [i for i, r in enumerate(rows) if "conv_in_kernel" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "ldm::conv_in" in r["Kernel_Name"]]
     seg = rows[idx[-2]:idx[-1]]
     wall = int(rows[idx[-1]]["Start_Timestamp"]) - int(seg[0]["Start_Timestamp"])
     busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg)
