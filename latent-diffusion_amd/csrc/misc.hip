@@ -387,6 +387,90 @@ conv_out_lanes_kernel(const TX* __restrict__ x, const float* __restrict__ w, con
   }
 }
 
+// Final conv, four horizontally adjacent pixels per 16-lane group: the filter words a lane reads from LDS serve four
+// outputs and the six input positions of a row serve three taps each (the one-pixel form issues 72 ds_read_b128 and 9
+// 16-byte loads per pixel and chunk; this one 18 and 4.5).  Needs wd % 4 == 0.  Same summation order per output.
+template <typename TX, typename TO, int COUT>
+__global__ void __launch_bounds__(256)
+conv_out_lanes4_kernel(const TX* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, TO* __restrict__ out,
+                       int batch, int cin, int h, int wd) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* wl = reinterpret_cast<float*>(smem_raw);  // [9][COUT][rowf], rows padded as in conv_out_lanes_kernel
+  const int rowf = cin + (cin >> 6) * 4 + 4;
+  for (int i = threadIdx.x; i < 9 * cin * COUT; i += 256) {
+    const int tap = i % 9, c = (i / 9) % cin, co = i / (9 * cin);   // w is [COUT][cin][3][3]: coalesced read
+    wl[(tap * COUT + co) * rowf + c + (c >> 6) * 4] = w[i];
+  }
+  __syncthreads();
+  const int sub = threadIdx.x & 15;
+  const int chunks = cin >> 3;
+  const unsigned wq = (unsigned)wd >> 2;
+  const unsigned nquad = (unsigned)batch * h * wq;   // < 2^31 (checked on the host)
+  const unsigned stride = gridDim.x * 16;
+  for (unsigned base = blockIdx.x * 16; base < nquad; base += stride) {
+    const unsigned quad = base + (threadIdx.x >> 4);
+    const bool live = quad < nquad;                  // whole 16-lane groups stay in the loop for the butterfly
+    const unsigned prow = quad / wq;
+    const int ow0 = (int)(quad - prow * wq) * 4;
+    const int b = (int)(prow / (unsigned)h);
+    const int oh = (int)(prow - (unsigned)b * h);
+    float acc[4][COUT];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) acc[q][co] = 0.f;
+    if (live) {
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh + kh - 1;
+        if (ih < 0 || ih >= h) continue;
+        const TX* row = x + (((size_t)b * h + ih) * wd) * cin;
+        for (int ch = sub; ch < chunks; ch += 16) {
+          float v[6][8];
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const int iw = ow0 + e - 1;
+            if (iw >= 0 && iw < wd) {
+              load8(row + (size_t)iw * cin + ch * 8, v[e]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[e][j] = 0.f;
+            }
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const float* wp = wl + (size_t)(kh * 3 + kw) * COUT * rowf + ch * 8 + (ch >> 3) * 4;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+              float wv[8];
+              load8(wp + co * rowf, wv);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[q][co] += v[q + kw][j] * wv[j];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[q][co] += __shfl_xor(acc[q][co], o, 16);
+      }
+    const int co_s = sub >> 2, q_s = sub & 3;
+    if (live && co_s < COUT) {
+      float r = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) r = (q == q_s && co == co_s) ? acc[q][co] : r;
+      Elem<TO>::st(out + (((size_t)b * COUT + co_s) * h + oh) * wd + ow0 + q_s, r + bias[co_s]);
+    }
+  }
+}
+
 template <typename T>
 __global__ void silu_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,11 +591,13 @@ static int conv_out_dispatch(const void* x, const float* w, const float* bias, v
   dim3 grid(blocks_for(npix)), block(256);
   const size_t lds = (size_t)9 * cout * (cin + (cin >> 6) * 4 + 4) * sizeof(float);
   if (npix >= 65536 && npix < (1LL << 31) && lds <= 65536 && cout <= 4) {   // large images: 16 lanes per pixel, filter in LDS
-    int64_t nb = (npix + 15) / 16;
+    const bool quad = wd % 4 == 0;                   // four pixels per 16-lane group
+    int64_t nb = ((quad ? npix / 4 : npix) + 15) / 16;
     if (nb > 8192) nb = 8192;                        // grid-stride: the LDS filter image is filled once per workgroup
     const dim3 g((unsigned)nb);
 #define LDM_CONV_OUT_LANES(CO) \
-  hipLaunchKernelGGL((conv_out_lanes_kernel<TX, TO, CO>), g, block, lds, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd)
+  if (quad) hipLaunchKernelGGL((conv_out_lanes4_kernel<TX, TO, CO>), g, block, lds, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd); \
+  else hipLaunchKernelGGL((conv_out_lanes_kernel<TX, TO, CO>), g, block, lds, st, (const TX*)x, w, bias, (TO*)out, batch, cin, h, wd)
     switch (cout) {
       case 1: LDM_CONV_OUT_LANES(1); break;
       case 2: LDM_CONV_OUT_LANES(2); break;

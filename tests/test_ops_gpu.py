@@ -555,7 +555,8 @@ def test_timestep_embedding(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 320), (1, 7, 9, 32), (2, 64, 64, 320), (2, 48, 52, 64), (1, 66, 66, 320)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 320), (1, 7, 9, 32), (2, 64, 64, 320), (2, 48, 52, 64), (1, 66, 66, 320),
+                                     (4, 128, 128, 64), (1, 262, 254, 32)])   # >= 65,536 pixels: the 16-lanes-per-pixel final conv
 def test_conv_in_out(dtype, B, H, W, C):
     ops = _ops()
     x = seeded((B, 4, H, W), 1)
