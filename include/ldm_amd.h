@@ -206,6 +206,18 @@ int ldm_groupnorm_apply(const void* a0, const void* a1, int c0, int c1, int dtyp
 int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups, float eps,
                   const float* gamma, const float* beta, int silu, void* out, float* stats, float* workspace, void* stream);
 
+/* ldm_groupnorm for callers that cannot allocate or lend device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments and bit-identical results as
+ * ldm_groupnorm, minus the workspace: the partial sums of the three-kernel form go to a static device array inside the
+ * library (LDM_GROUPNORM_NOALLOC_MAX_FLOATS floats = 4 MiB, held by every GPU the library runs on until the process ends).
+ * The call makes no hipMalloc / hipFree and calls no allocating routine.  LDM_EINVAL if batch * groups exceeds
+ * LDM_GROUPNORM_NOALLOC_MAX_FLOATS / 128 (= 8192; e.g. 256 samples x 32 groups).  All calls on one GPU share that GPU's
+ * array: calls that overlap on one GPU (two streams) race; calls ordered on one stream do not.  Nothing in the array has to be
+ * zero on entry (every word read is written earlier in the same call). */
+#define LDM_GROUPNORM_NOALLOC_MAX_FLOATS (1 << 20)
+int ldm_groupnorm_noalloc(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups, float eps,
+                          const float* gamma, const float* beta, int silu, void* out, float* stats, void* stream);
+
 /* Row-wise LayerNorm over the last dimension (unet.py:550-551, :576), eps 1e-5. */
 int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,
                   const float* beta, void* out, void* stream);

@@ -2,6 +2,8 @@
 // All of these are HBM-bound streaming kernels: 16-byte vector accesses, fp32 statistics.
 #include "common.h"
 
+#include <mutex>
+
 namespace ldm {
 
 constexpr int GN_THREADS = 256;
@@ -567,6 +569,58 @@ extern "C" int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int
   const int rc = ldm_groupnorm_stats(a0, a1, c0, c1, dtype, batch, hw, groups, eps, stats, workspace, stream);
   if (rc) return rc;
   return ldm_groupnorm_apply(a0, a1, c0, c1, dtype, batch, hw, groups, stats, gamma, beta, silu, out, stream);
+}
+
+// ------------------------------------------------------------------- GroupNorm without a caller workspace
+// ldm_groupnorm_noalloc: the partial-sum workspace of the three-kernel form lives in a file-scope device array of this code
+// object, so the call neither takes nor allocates scratch memory.  `scratch` is only a host-side stand-in for the symbol:
+// the device address is looked up once per GPU (every GPU holds its own copy at its own address) and that pointer, never
+// the array's name, is what the kernels receive.
+static __device__ __align__(256) float scratch[LDM_GROUPNORM_NOALLOC_MAX_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+float* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_for_current_device(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("ldm_groupnorm_noalloc: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    return LDM_EHIP;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* ptr = nullptr;
+    e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || ptr == nullptr) {
+      set_error("ldm_groupnorm_noalloc: hipGetSymbolAddress(scratch) on device %d: %s", dev, hipGetErrorString(e));
+      return LDM_EHIP;
+    }
+    g_scratch_ptr[dev] = static_cast<float*>(ptr);
+  }
+  *out = g_scratch_ptr[dev];
+  return LDM_OK;
+}
+}  // namespace
+
+extern "C" int ldm_groupnorm_noalloc(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups,
+                                     float eps, const float* gamma, const float* beta, int silu, void* out, float* stats,
+                                     void* stream) {
+  LDM_REQUIRE(batch >= 0 && groups >= 1, "ldm_groupnorm_noalloc: bad sizes");
+  if (batch == 0) return LDM_OK;
+  const long long need = (long long)batch * groups * 2 * GN_MAX_SLABS;
+  LDM_REQUIRE(need <= (long long)LDM_GROUPNORM_NOALLOC_MAX_FLOATS,
+              "ldm_groupnorm_noalloc: batch %d x %d groups needs %lld scratch floats, the built-in buffer holds %d "
+              "(batch * groups <= %d); use ldm_groupnorm with a caller workspace",
+              batch, groups, need, (int)LDM_GROUPNORM_NOALLOC_MAX_FLOATS, (int)(LDM_GROUPNORM_NOALLOC_MAX_FLOATS / (2 * GN_MAX_SLABS)));
+  float* ws = nullptr;
+  const int rc = scratch_for_current_device(&ws);
+  if (rc) return rc;
+  // Nothing in the buffer has to start at zero: gn_partial_kernel writes every (sample, slab, group) pair that
+  // gn_finalize_kernel reads in the same call.
+  return ldm_groupnorm(a0, a1, c0, c1, dtype, batch, hw, groups, eps, gamma, beta, silu, out, stats, ws, stream);
 }
 
 extern "C" int ldm_layernorm(const void* x, int dtype, int64_t rows, int cols, float eps, const float* gamma,

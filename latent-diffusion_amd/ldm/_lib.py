@@ -89,6 +89,8 @@ _SIGNATURES = {
                             c_void_p, c_int, c_void_p, c_void_p],
     "ldm_groupnorm": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
                       c_void_p, c_void_p, c_void_p, c_void_p],
+    "ldm_groupnorm_noalloc": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p],
     "ldm_layernorm": [c_void_p, c_int, c_i64, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p],
     "ldm_attention": [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                       c_int, c_int, c_void_p],
