@@ -63,19 +63,51 @@ def _require_gpu(*tensors):
             raise RuntimeError("ldm_amd DDPMScheduler: tensors must live on an AMD GPU (there is no CPU fallback)")
 
 
-def _betas_f64(schedule: str, T: int) -> torch.Tensor:
-    """float64 beta schedules (:308-357) with torch-CPU ops, so that every rounding matches the reference's."""
-    if schedule == "linear":
-        k = 1000 / T
-        return torch.linspace(k * 0.0001, k * 0.02, T, dtype=torch.float64)
-    u = torch.linspace(0, T, T + 1, dtype=torch.float64) / T
-    if schedule == "cosine":
-        acp = torch.cos((u + 0.008) / 1.008 * math.pi * 0.5) ** 2
-    else:  # sigmoid, start=-3 end=3 tau=1; the two end values are float32 scalars in the reference
-        lo, hi = torch.tensor(-3.0).sigmoid(), torch.tensor(3.0).sigmoid()
-        acp = (-(u * 6 - 3).sigmoid() + hi) / (hi - lo)
+# ---- the module-level helpers of the reference file (:285-357), same names, arguments and results
+def extract(a: torch.Tensor, t: torch.Tensor, x_shape) -> torch.Tensor:
+    """a[t] reshaped to (b, 1, ..., 1) so that it broadcasts against a tensor of shape ``x_shape`` (:285-305)."""
+    b = t.shape[0]
+    return a.gather(-1, t).reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def linear_beta_schedule(timesteps: int) -> torch.Tensor:
+    """float64 betas of the original DDPM paper, end points scaled by 1000 / T (:308-315)."""
+    k = 1000 / timesteps
+    return torch.linspace(k * 0.0001, k * 0.02, timesteps, dtype=torch.float64)
+
+
+def _betas_from_alphas_cumprod(acp: torch.Tensor) -> torch.Tensor:
     acp = acp / acp[0]
     return torch.clip(1 - (acp[1:] / acp[:-1]), 0, 0.999)
+
+
+def cosine_beta_schedule(timesteps: int, s: float = 0.008) -> torch.Tensor:
+    """:318-328."""
+    u = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    return _betas_from_alphas_cumprod(torch.cos((u + s) / (1 + s) * math.pi * 0.5) ** 2)
+
+
+def sigmoid_beta_schedule(timesteps: int, start=-3, end=3, tau=1, clamp_min=1e-5) -> torch.Tensor:
+    """:331-343; the two end values are float32 scalars in the reference (``clamp_min`` is unused there too)."""
+    u = torch.linspace(0, timesteps, timesteps + 1, dtype=torch.float64) / timesteps
+    lo, hi = torch.tensor(start / tau).sigmoid(), torch.tensor(end / tau).sigmoid()
+    return _betas_from_alphas_cumprod((-((u * (end - start) + start) / tau).sigmoid() + hi) / (hi - lo))
+
+
+def get_beta_schedule(beta_schedule: str, timesteps: int) -> torch.Tensor:
+    """:346-357."""
+    if beta_schedule == "linear":
+        return linear_beta_schedule(timesteps)
+    if beta_schedule == "cosine":
+        return cosine_beta_schedule(timesteps)
+    if beta_schedule == "sigmoid":
+        return sigmoid_beta_schedule(timesteps)
+    raise ValueError(f"unknown beta schedule {beta_schedule}")
+
+
+def _betas_f64(schedule: str, T: int) -> torch.Tensor:
+    """float64 beta schedules (:308-357) with torch-CPU ops, so that every rounding matches the reference's."""
+    return get_beta_schedule(schedule, T)
 
 
 def _host_tables(schedule: str, T: int) -> dict:

@@ -598,3 +598,85 @@ def test_pack_weight_pair_matches_the_two_single_packs(dtype, shape, glu):
         ops.pack_weight_pair(w2, dtype, fwd=f[shape[0]:], dgrad=d[:, shape[0]:])
         cat = torch.cat([w, w2], 0)
         assert torch.equal(f, ops.pack_weight(cat, dtype)) and torch.equal(d, ops.pack_weight_dgrad(cat, dtype))
+
+
+# ------------------------------------------------------------------- the BENCHMARKED shapes (round 2)
+def _attn_ref_by_head(qr, kvr, heads, dout=None):
+    """float32 torch-CPU softmax(QK^T/sqrt d)V, one head at a time (the 9,216-token score matrix of one head is 340 MB);
+    with dout also the gradients (dq, dkv) by autograd, head by head."""
+    B, L, C = qr.shape
+    d = C // heads
+    out = torch.empty_like(qr)
+    dq = torch.zeros_like(qr) if dout is not None else None
+    dkv = torch.zeros_like(kvr) if dout is not None else None
+    for b in range(B):
+        for h in range(heads):
+            sl = slice(h * d, (h + 1) * d)
+            q = qr[b, :, sl].clone().requires_grad_(dout is not None)
+            k = kvr[b, :, sl].clone().requires_grad_(dout is not None)
+            v = kvr[b, :, C + h * d:C + (h + 1) * d].clone().requires_grad_(dout is not None)
+            o = torch.softmax(q @ k.t() / math.sqrt(d), dim=-1) @ v
+            out[b, :, sl] = o.detach()
+            if dout is not None:
+                o.backward(dout[b, :, sl])
+                dq[b, :, sl] = q.grad
+                dkv[b, :, sl] = k.grad
+                dkv[b, :, C + h * d:C + (h + 1) * d] = v.grad
+    return out, dq, dkv
+
+
+@pytest.mark.parametrize("L,Lk", [(4096, 4096), (9216, 9216), (4096, 77)])
+def test_attention_headline_lengths_d40(L, Lk):
+    """d = 40 self-attention at the token counts that are benchmarked: 4,096 (64x64 latents, 16 % of the configs[1] step,
+    unet.py:678) and 9,216 (96x96, configs[4]); forward (inference and training form + lse) and backward, bf16, against
+    float32 torch on the same bf16-rounded operands."""
+    ops = _ops()
+    B, C, heads = 1, 320, 8
+    q, qr = _q(seeded((B, L, C), 1), torch.bfloat16)
+    kv, kvr = _q(seeded((B, Lk, 2 * C), 2), torch.bfloat16)
+    do, dor = _q(seeded((B, L, C), 3), torch.bfloat16)
+    ref, dq_ref, dkv_ref = _attn_ref_by_head(qr, kvr, heads, dor)
+    y = ops.attention(q, kv, heads)
+    assert rel_l2(y, ref) < TOL[torch.bfloat16]
+    y2, lse = ops.attention_train(q, kv, heads)
+    assert torch.equal(y2, y)
+    d = C // heads
+    s0 = (qr[0, :, :d] @ kvr[0, :, :d].t()) * (math.log2(math.e) / math.sqrt(d))
+    # d = 40: the kernel folds log2(e)/sqrt(d) into a bf16-rounded copy of Q, so its scores carry 2^-9 relative rounding
+    assert torch.allclose(lse[0, 0].cpu(), torch.logsumexp(s0 * math.log(2.0), dim=-1) / math.log(2.0), atol=3e-2, rtol=0)
+    dq, dkv = ops.attention_backward(q, kv, y2, do, lse, heads)
+    assert rel_l2(dq, dq_ref) < 1e-2 and rel_l2(dkv, dkv_ref) < 1e-2
+
+
+def test_conv3x3_headline_rows():
+    """The implicit-GEMM 3x3 conv at configs[1]'s largest row count: 320 -> 320 channels, 64x64, B = 32, i.e. M = 131,072
+    rows x K = 2,880 (unet.py:702/:708 at level 0), bf16, with bias + time-embedding row vector + residual; checked against
+    F.conv2d on three whole samples of the batch (first, middle, last: every tile row band and the M edge)."""
+    ops = _ops()
+    B, C, H = 32, 320, 64
+    x, xr = _q(nhwc(seeded((B, C, H, H), 1)), torch.bfloat16)
+    w = seeded((C, C, 3, 3), 2) / math.sqrt(9 * C)
+    b = seeded((C,), 3)
+    rv, rvr = _q(seeded((B, C), 4), torch.bfloat16)
+    res, resr = _q(nhwc(seeded((B, C, H, H), 5)), torch.bfloat16)
+    wp = ops.pack_weight(w.cuda(), torch.bfloat16)
+    y = ops.conv_gemm(x, wp, ksize=3, bias=b.cuda(), rowvec=rv, residual=res)
+    assert y.shape == (B, H, H, C)
+    wr = w.bfloat16().float()
+    for s in (0, 13, 31):
+        ref = F.conv2d(xr[s:s + 1].permute(0, 3, 1, 2), wr, b, padding=1) + rvr[s][None, :, None, None]
+        ref = nhwc(ref) + resr[s:s + 1]
+        assert rel_l2(y[s:s + 1], ref) < TOL[torch.bfloat16], s
+    # the K = 320 projections of the same level (q|k|v: N = 960; GEGLU: N = 2560) on the same 131,072 rows
+    xm = x.view(B * H * H, C)
+    wq = seeded((960, C), 6) / math.sqrt(C)
+    yq = ops.conv_gemm(xm, ops.pack_weight(wq.cuda(), torch.bfloat16))
+    rows = torch.tensor([0, 1, 4095, 4096, 70000, 131071])
+    assert rel_l2(yq[rows.cuda()], F.linear(xr.view(-1, C)[rows], wq.bfloat16().float())) < TOL[torch.bfloat16]
+    wg = seeded((2560, C), 7) / math.sqrt(C)
+    bg = seeded((2560,), 8)
+    yg = ops.conv_gemm(xm, ops.pack_weight(wg.cuda(), torch.bfloat16, glu_pairs=True),
+                       bias=ops.pack_weight(bg.cuda(), torch.float32, glu_pairs=True).flatten(), glu="geglu")
+    full = F.linear(xr.view(-1, C)[rows], wg.bfloat16().float(), bg)
+    val, gate = full.chunk(2, dim=-1)
+    assert rel_l2(yg[rows.cuda()], val * F.gelu(gate)) < TOL[torch.bfloat16]

@@ -184,3 +184,67 @@ def test_trajectory_teacher_forced(golden):
         prev, _ = sref.step(tabs, g[f"eps.{i}"], t, sref.previous_timestep(ts, t, True), lat_in,
                             seeded((4, 4, 32, 32), 1000 + i))
         assert same_bits(prev, g[f"lat.{i}"])
+
+
+# ------------------------------------------------------------------------- round 2: S5 and the new fixtures
+def _s5_inputs(g):
+    return g["x_t"], g["x0"], g["noise"], g["t"], g["s"]
+
+
+@pytest.mark.parametrize("sched", ["linear", "cosine"])
+def test_s5_methods_oracle_and_product_host_side(golden, sched):
+    """S5 (scheduling_ddpm.py:103-129, :217-256): the oracle restatement and the product's methods (plain torch ops,
+    here on CPU tensors) against the reference's outputs, bit for bit; per-sample t, s = -1 on the last sample."""
+    from ldm.scheduling_ddpm import DDPMScheduler
+    g = golden("scheduler_s5.npz")
+    x_t, x0, nz, t, s = _s5_inputs(g)
+    tabs = sref.build_tables(sched, 1000)
+    sch = DDPMScheduler(beta_schedule=sched, device=torch.device("cpu"))
+    for name, fn in (("oracle", None), ("product", sch)):
+        if fn is None:
+            got = {"start": sref.predict_start_from_noise(tabs, x_t, t, nz), "noise": sref.predict_noise_from_start(tabs, x_t, t, x0)}
+            got["qp.mean"], got["qp.std"] = sref.q_posterior(tabs, x0, x_t, t)
+            got["qb.mean"], got["qb.std"] = sref.q_posterior_between(tabs, x0, x_t, t, s)
+        else:
+            got = {"start": fn.predict_start_from_noise(x_t, t, nz), "noise": fn.predict_noise_from_start(x_t, t, x0)}
+            got["qp.mean"], got["qp.std"] = fn.q_posterior(x0, x_t, t)
+            got["qb.mean"], got["qb.std"] = fn.q_posterior_between(x0, x_t, t, s)
+        for k, v in got.items():
+            assert same_bits(v, g[f"{sched}.{k}"]), (name, sched, k)
+    assert same_bits(sch.scale_model_input(x_t, 5), x_t)
+
+
+def test_scheduler_module_level_helpers(golden):
+    """extract / linear_ / cosine_ / sigmoid_beta_schedule / get_beta_schedule of the drop-in module (:285-357)."""
+    import ldm.scheduling_ddpm as S
+    g = golden("scheduler_s5.npz")
+    for sched, fn in (("linear", S.linear_beta_schedule), ("cosine", S.cosine_beta_schedule), ("sigmoid", S.sigmoid_beta_schedule)):
+        for T in (1000, 250):
+            b = S.get_beta_schedule(sched, T)
+            assert b.dtype == torch.float64 and same_bits(b, g[f"betas64.{sched}.{T}"]) and same_bits(fn(T), b)
+            assert same_bits(sref.betas_f64(sched, T), b)
+    with pytest.raises(ValueError):
+        S.get_beta_schedule("bogus", 10)
+    a = torch.arange(10, dtype=torch.float32)
+    e = S.extract(a, torch.tensor([3, 0, 9]), (3, 4, 8, 8))
+    assert e.shape == (3, 1, 1, 1) and e.flatten().tolist() == [3.0, 0.0, 9.0]
+
+
+def test_well_conditioned_filler_small(golden):
+    """unet_wellcond.npz: the oracle on the well-conditioned filler reproduces the reference's float32 output, and that
+    filler leaves every tensor but the gate halves of the GLU projections untouched."""
+    g = golden("unet_wellcond.npz")
+    cfg = uref.UNetConfig(**SMALL)
+    shapes = uref.param_shapes(cfg)
+    sd = uref.fill_state_dict(shapes, seed=7, **uref.WELL_CONDITIONED)
+    plain = uref.fill_state_dict(shapes, seed=7, gain=1.0)
+    changed = [k for k in sd if not torch.equal(sd[k], plain[k])]
+    assert changed and all(".w1_w2." in k for k in changed)
+    k = changed[0]
+    half = sd[k].shape[0] // 2
+    assert torch.equal(sd[k][:half], plain[k][:half])
+    x, ctx = seeded((4, 4, 32, 32), 11), seeded((4, 77, 768), 12)
+    with torch.no_grad():
+        y = uref.unet_forward(sd, cfg, x, torch.tensor([999, 500, 20, 0]), ctx)
+    assert rel_l2(y, g["small.out"]) < 1e-5 and rel_l2(y, g["small.out_f64"]) < 1e-5
+    assert float(g["small.err_torch_bf16"]) < 4e-2 and float(g["traj.psnr_torch_bf16"]) > 40.0

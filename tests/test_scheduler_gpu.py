@@ -3,7 +3,7 @@ vectors taken from the reference.
 
 Tolerance: BIT-EXACT against the oracle evaluated on the same host (float32 IEEE operations in the reference's
 order).  Against the golden files (generated in the build container) the tables that go through torch's CPU
-sqrt are allowed 4 ulp and what is computed from them 1e-5 relative L2: torch's CPU sqrt is MKL's, which is not correctly
+sqrt are allowed 1 ulp (4 ulp where a product and a quotient follow the square root) in at most 400 of 1000 entries and what is computed from them 1e-6 relative L2: torch's CPU sqrt is MKL's, which is not correctly
 rounded and differs between host CPUs (measured: 6/1000 entries of sqrt_alphas_cumprod differ by 1 ulp between
 the build container and the GPU box), so the reference itself is only reproducible to that level across hosts.
 betas, alphas_cumprod and the timestep lists are bit-exact against the golden files everywhere."""
@@ -32,7 +32,14 @@ def test_tables_on_device_bit_exact(golden, sched):
         if k in ("betas", "alphas_cumprod"):
             assert same_bits(getattr(sched, k), g[f"linear.{k}"]), k
         else:
-            assert max_ulp(getattr(sched, k), g[f"linear.{k}"]) <= 4, k
+            # torch's CPU sqrt (MKL) on this host against the build container's: never more than 1 ulp, in a minority of the
+            # entries (measured on boxes of the pool: 6 and 187 of 1000 for sqrt_alphas_cumprod -- it depends on the host CPU)
+            dev, ref = getattr(sched, k).cpu(), g[f"linear.{k}"]
+            ndiff = int((dev != ref).sum())
+            print(f"{k}: {ndiff}/1000 entries differ from the build container's by 1 ulp")
+            # a table that IS a square root: 1 ulp; posterior_mean_coef1/2 multiply and divide a 1-ulp-off square root: 4
+            assert max_ulp(dev, ref) <= (4 if k.startswith("posterior_mean") else 1), k
+            assert ndiff <= 400, (k, ndiff)
 
 
 @pytest.mark.parametrize("schedule", ["linear", "cosine"])
@@ -50,8 +57,8 @@ def test_step_golden_bit_exact(golden, schedule):
         ref_prev, ref_x0 = sref.step(tabs, g["eps"], t, sref.previous_timestep(ts, t, True), g["x_t"], g["noise"])
         assert same_bits(out.prev_sample, ref_prev), t
         assert same_bits(out.pred_original_sample, ref_x0), t
-        assert rel_l2(out.prev_sample, g[f"step.{schedule}.{t}.prev"]) < 1e-5, t
-        assert rel_l2(out.pred_original_sample, g[f"step.{schedule}.{t}.x0"]) < 1e-5, t
+        assert rel_l2(out.prev_sample, g[f"step.{schedule}.{t}.prev"]) < 1e-6, t
+        assert rel_l2(out.pred_original_sample, g[f"step.{schedule}.{t}.x0"]) < 1e-6, t
 
 
 def test_step_iterating_device_timesteps_no_sync(golden, sched):
@@ -183,3 +190,36 @@ def test_fused_training_input_prep_matches_the_reference_sequence():
     ref = enc.clone()
     ref[mask] = null
     assert torch.equal(train_inputs.drop_conditioning(enc, null, mask), ref)
+
+
+@pytest.mark.parametrize("schedule", ["linear", "cosine"])
+def test_s5_methods_on_device(golden, schedule):
+    """S5 (scheduling_ddpm.py:103-129, :217-256) on GPU tensors: table gathers and float32 elementwise arithmetic, so
+    bit-exact against the reference wherever no device sqrt is involved (predict_*, q_posterior); q_posterior_between takes
+    two square roots on the device -- IEEE-exact there, MKL's on the reference's CPU -- hence 1e-6."""
+    from ldm.scheduling_ddpm import DDPMScheduler
+    g = golden("scheduler_s5.npz")
+    sch = DDPMScheduler(beta_schedule=schedule, device=torch.device("cuda"))
+    x_t, x0, nz, t, s = (g[k].cuda() for k in ("x_t", "x0", "noise", "t", "s"))
+    tabs = sref.build_tables(schedule)
+    a = sch.predict_start_from_noise(x_t, t, nz)
+    b = sch.predict_noise_from_start(x_t, t, x0)
+    assert same_bits(a, sref.predict_start_from_noise(tabs, g["x_t"], g["t"], g["noise"]))
+    assert same_bits(b, sref.predict_noise_from_start(tabs, g["x_t"], g["t"], g["x0"]))
+    assert rel_l2(a, g[f"{schedule}.start"]) < 1e-6 and rel_l2(b, g[f"{schedule}.noise"]) < 1e-6
+    m, sd = sch.q_posterior(x0, x_t, t)
+    rm, rs = sref.q_posterior(tabs, g["x0"], g["x_t"], g["t"])
+    assert same_bits(m, rm) and same_bits(sd, rs)
+    assert rel_l2(m, g[f"{schedule}.qp.mean"]) < 1e-6 and rel_l2(sd, g[f"{schedule}.qp.std"]) < 1e-6
+    m, sd = sch.q_posterior_between(x0, x_t, t, s)
+    assert m.shape == x_t.shape and sd.shape == (5, 1, 1, 1)
+    assert rel_l2(m, g[f"{schedule}.qb.mean"]) < 1e-6 and rel_l2(sd, g[f"{schedule}.qb.std"]) < 1e-6
+    # the last sample has s = -1: alpha_bar_{-1} := 1, std floor sqrt(1e-20)
+    assert abs(float(sd[4]) - 1e-10) < 1e-16
+    # step() == predict_start_from_noise + q_posterior_between + noise (how the reference composes it, :207-212)
+    sch.set_timesteps(50)
+    out = sch.step(nz, 500, x_t, noise=x0)
+    tt, ss = torch.full((5,), 500, device="cuda"), torch.full((5,), 480, device="cuda")
+    x0p = sch.predict_start_from_noise(x_t, tt, nz)
+    mean, std = sch.q_posterior_between(x0p, x_t, tt, ss)
+    assert rel_l2(out.prev_sample, mean + std * x0) < 1e-6
