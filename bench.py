@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """Headline benchmark: UNet denoise img-steps/sec at 64x64 latents on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch: ``UNet.forward`` (SD-1.5-shaped, bf16 storage / fp32
-accumulate) on 32 latents of 4x64x64 with a 77x768 text context, followed by ``DDPMScheduler.step`` on the
-result -- BASELINE.json configs[1], the configuration the metric is quoted on.  Inputs are resident in HBM before
-the timed region.  With --gpus N every rank runs the same per-GPU workload on its own batch shard (independent
-latents, no data-path collective: weak scaling); value = images x steps over all ranks / max-over-ranks time.
+Default mode -- one "step" = one pass of the hot path over one batch: ``UNet.forward`` (SD-1.5-shaped, bf16 storage / fp32
+accumulate) on 32 latents of 4x64x64 with a 77x768 text context, followed by ``DDPMScheduler.step`` on the result --
+BASELINE.json configs[1], the configuration the metric is quoted on.  Inputs are resident in HBM before the timed region.
+With --gpus N every rank runs the same per-GPU workload on its own batch shard (independent latents, no data-path
+collective: weak scaling); value = images x steps over all ranks / max-over-ranks time.
+
+Other modes (same launch contract, same JSON schema):
+  --strong   BASELINE.json configs[2]: 256 latents of 4x64x64 sharded over the N ranks (256/N each, run in micro-batches
+             of 32), K reverse steps of the sampling loop timed; "scaling": "strong" (total work fixed as N grows).
+  --train    BASELINE.json configs[3]: the reference's train step (add_noise -> bf16 forward -> MSE -> backward with the
+             bucketed RCCL gradient all-reduce -> clip -> AdamW), 32 latents per GPU; value in img/s; "scaling": "weak".
 
 Printed JSON (rank 0, one line) also carries
-  roofline      the dominant kernel (bf16 implicit-GEMM conv/linear): algorithmic FLOPs per launch / its average
-                launch duration, measured with HIP events on the launch stream inside the timed region,
-                against the dense bf16 MFMA peak;
+  roofline      the dominant kernel (bf16 implicit-GEMM conv/linear; in --train possibly the weight-gradient kernel):
+                algorithmic FLOPs per launch / its average launch duration, measured with HIP events on the launch
+                stream inside the timed region, against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch from the
+                rocprofv3 --pmc passes recorded in bench_pmc_traffic.json (tools/profile_bench.sh writes it), reported only
+                while the kernel sources still hash to what was profiled -- else null;
   cpu_baseline  the CPU oracle (oracle/unet_ref.py + scheduler_ref.py: a port, not the product) timed on this
-                host's cores on a bounded sample of the same workload (N=1 only).
+                host's cores on a bounded sample of the same workload (N=1, default mode only).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -32,6 +41,7 @@ sys.path.insert(0, ROOT)
 MFMA_BF16_DENSE_PEAK = 2.5e15       # FLOP/s, /opt/skills/guides/MI355X_MICROARCH.md (dense; 2:1-sparse figure is 5e15)
 FLOPS_PER_IMAGE_64 = 803273441280.0  # algorithmic forward FLOPs per latent at 64x64 (tests/golden/meta.json)
 BATCH, LATENT, CTX_LEN, CTX_DIM = 32, 64, 77, 768
+STRONG_LATENTS, STRONG_MICRO_BATCH = 256, 32
 
 
 def init_weights_(net: torch.nn.Module, seed: int):
@@ -74,15 +84,70 @@ def cpu_baseline(sample_forwards: int = 12):
                       f"after 1 warm-up, {dt:.1f} s; os.cpu_count()={os.cpu_count()}"}
 
 
+def kernel_source_hash() -> str:
+    """Hash of the kernel sources a PMC figure is valid for (bench_pmc_traffic.json carries the hash it was taken on)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "latent-diffusion_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kernel: str, workload_key: str):
+    """(bytes per launch, note) from the committed rocprofv3 --pmc passes, or (None, why)."""
+    path = os.path.join(ROOT, "bench_pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None, "no bench_pmc_traffic.json (run tools/profile_bench.sh on the GPU box)"
+    if rec.get("source_hash") != kernel_source_hash():
+        return None, f"kernel sources changed since the PMC passes of {rec.get('profile', '?')}"
+    ent = rec.get("workloads", {}).get(workload_key, {}).get(kernel)
+    if ent is None:
+        return None, f"kernel not in the PMC passes of {rec.get('profile', '?')} for workload {workload_key}"
+    return float(ent["hbm_bytes_per_launch"]), (f"FETCH_SIZE (doubled: gfx950 correction) + WRITE_SIZE per launch, separate rocprofv3 --pmc "
+                                                f"passes, {rec.get('profile', '?')}; Infinity-Cache hits included (upper bound of DRAM bytes)")
+
+
+def roofline_from_log(log, elapsed, workload_key):
+    per = {}
+    for name, flops, e0, e1, _shape in log:
+        d = per.setdefault(name, [0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += flops
+        d[2] += e0.elapsed_time(e1) * 1e-3
+    gemm_time = sum(d[2] for d in per.values())
+    dom = max(per, key=lambda k: per[k][2])
+    n_l, fl, tt = per[dom]
+    achieved = fl / tt
+    traffic, note = pmc_traffic(dom, workload_key)
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": traffic, "traffic_note": note,
+            "launches": n_l, "avg_launch_us": round(1e6 * tt / n_l, 1),
+            "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 2),
+            "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
+                                     "avg_us": round(1e6 * v[2] / v[0], 1)} for k, v in sorted(per.items())}}
+    return roof, gemm_time / elapsed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 10; 5 with --train)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 3; 2 with --train)")
     ap.add_argument("--batch", type=int, default=BATCH, help="latents per GPU (default: the metric's 32)")
     ap.add_argument("--latent", type=int, default=LATENT, help="latent extent (default 64: the metric's; 96 = BASELINE configs[4])")
+    ap.add_argument("--strong", action="store_true", help="configs[2]: 256 latents sharded over the ranks, strong scaling")
+    ap.add_argument("--train", action="store_true", help="configs[3]: the training step, 32 latents per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.strong and args.train:
+        raise SystemExit("--strong and --train are exclusive")
+    if args.steps is None:
+        args.steps = 5 if args.train else 10
+    if args.warmup is None:
+        args.warmup = 2 if args.train else 3
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,11 +181,20 @@ def main():
         net = UNet()
     net = net.to_empty(device=dev)
     init_weights_(net, seed=1234)
-    net.eval()
     sched = DDPMScheduler(device=dev)
-    sched.set_timesteps(50, device=dev)
 
-    B = args.batch
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(elapsed):
+        if dist is None:
+            return elapsed
+        tmax = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax)
+
     LAT = args.latent
     if LAT == 64:
         flops_per_image = FLOPS_PER_IMAGE_64
@@ -128,84 +202,129 @@ def main():
         from oracle import unet_ref as uref
         flops_per_image = uref.flops_per_image(uref.UNetConfig(), LAT, LAT)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)  # every rank owns different latents (batch shard)
-    lat0 = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
-    ctx = torch.randn(B, CTX_LEN, CTX_DIM, device=dev, generator=gen).bfloat16()
-    noise = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
-    ts = sched.timesteps
+    log = []
+    out = None
 
-    def one_step(lat, i):
-        t = ts[i % len(ts)]
-        eps = net(lat, t, ctx)                     # bf16 UNet forward (autocast; conv_in reads the fp32 latents directly)
-        return sched.step(eps, t, lat, noise=noise).prev_sample  # fp32 scheduler update, fused kernel
+    if args.train:
+        # ------------------------------------------------------------------ configs[3]: the training step
+        from ldm.optim import FusedAdamW, mse_loss
+        from ldm.parallel import DataParallel
+        net.train()
+        B = args.batch
+        model = DataParallel(net)
+        opt = FusedAdamW(net.parameters(), lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8, max_grad_norm=1.0)
+        lat = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
+        ctx = torch.randn(B, CTX_LEN, CTX_DIM, device=dev, generator=gen)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def train_step():
+            noise = torch.randn(lat.shape, device=dev, generator=gen)
+            t = torch.randint(0, 1000, (B,), device=dev, generator=gen)
+            noisy = sched.add_noise(lat, noise, t)                       # train_latent_diffusion.py:1062
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = model(noisy, t, ctx)                              # :1105
+            loss, dpred = mse_loss(pred.detach(), noise)                # :1108 and its gradient, one pass
+            pred.backward(dpred)                                         # :1119 (+ bucketed all-reduce when N > 1)
+            opt.step()                                                   # :1123-1124, clip folded into AdamW
+            opt.zero_grad(set_to_none=True)
+            return loss
 
-    with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
-        lat = lat0
-        for i in range(args.warmup):
-            lat = one_step(lat0, i)
-        log = []
+        for _ in range(args.warmup):
+            loss = train_step()
         ops.set_launch_log(log)
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            lat = one_step(lat0, i)
+        for _ in range(args.steps):
+            loss = train_step()
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(time.perf_counter() - t0)
         ops.set_launch_log(None)
-    assert torch.isfinite(lat).all(), "non-finite latents"
+        assert torch.isfinite(loss), "non-finite loss"
+        if rank == 0:
+            roof, share = roofline_from_log(log, elapsed, f"train_b{B}_l{LAT}")
+            flops = 3.0 * flops_per_image * B
+            out = {
+                "metric": f"UNet training img/s at {LAT}x{LAT} latents (noise-prediction MSE, bf16 compute / fp32 master, AdamW)",
+                "value": round(world * B * args.steps / elapsed, 2), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": "SD-1.5-shaped UNet (859.5M params, random init) training step: add_noise, bf16 forward, MSE, "
+                                       f"backward, gradient all-reduce (RCCL, 64 MiB buckets), clip 1.0, AdamW; batch {B} of 4x{LAT}x{LAT} "
+                                       "per GPU (BASELINE.json configs[3])",
+                           "per_gpu_batch": B, "global_batch": B * world, "latent": f"4x{LAT}x{LAT}",
+                           "parallelism": f"data parallel x{world}, bucketed gradient all-reduce overlapped with the backward",
+                           "collectives_per_backward": model.reducer.launched,
+                           "frac_of_mfma_peak_at_3x_forward_flops": round(flops / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
+                           "gemm_kernel_share_of_step": round(share, 3),
+                           "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+                           "loss": round(float(loss), 5)},
+                "roofline": roof}
+    else:
+        net.eval()
+        sched.set_timesteps(50, device=dev)
+        ts = sched.timesteps
+        if args.strong:
+            # ------------------------------------------ configs[2]: 256 latents sharded over the ranks, micro-batches of 32
+            from ldm.sampling import shard_range
+            lo, hi = shard_range(STRONG_LATENTS, rank, world)
+            chunks = [(c, min(c + STRONG_MICRO_BATCH, hi)) for c in range(lo, hi, STRONG_MICRO_BATCH)]
+            B = hi - lo
+        else:
+            B = args.batch
+            chunks = [(0, B)]
+        lat0 = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
+        ctx = torch.randn(B, CTX_LEN, CTX_DIM, device=dev, generator=gen).bfloat16()
+        noise = torch.randn(B, 4, LAT, LAT, device=dev, generator=gen)
+        base = chunks[0][0]
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax)
+        def one_step(i):
+            t = ts[i % len(ts)]
+            last = None
+            for c0, c1 in chunks:
+                s = slice(c0 - base, c1 - base)
+                eps = net(lat0[s], t, ctx[s])                 # bf16 UNet forward (autocast; conv_in reads the fp32 latents directly)
+                last = sched.step(eps, t, lat0[s], noise=noise[s]).prev_sample  # fp32 scheduler update, fused kernel
+            return last
 
+        with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+            for i in range(args.warmup):
+                lat = one_step(i)
+            ops.set_launch_log(log)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                lat = one_step(i)
+            barrier()
+            elapsed = time.perf_counter() - t0
+            ops.set_launch_log(None)
+        assert torch.isfinite(lat).all(), "non-finite latents"
+        elapsed = max_over_ranks(elapsed)
+        if rank == 0:
+            ms = 1e3 * elapsed / args.steps
+            total = STRONG_LATENTS if args.strong else world * B
+            headline = LAT == 64 and ((not args.strong and B == BATCH) or args.strong)
+            roof, share = roofline_from_log(log, elapsed, f"{'strong' if args.strong else 'fwd'}_b{min(B, STRONG_MICRO_BATCH) if args.strong else B}_l{LAT}")
+            if args.strong:
+                workload = (f"SD-1.5-shaped UNet (859.5M params, random init) bf16 denoise + DDPM scheduler step over {STRONG_LATENTS} latents of "
+                            f"4x{LAT}x{LAT} + 77x768 context, sharded {STRONG_LATENTS}/{world} per GPU in micro-batches of "
+                            f"{STRONG_MICRO_BATCH} (BASELINE.json configs[2])")
+            else:
+                workload = ("SD-1.5-shaped UNet (859.5M params, random init) bf16 forward + DDPM scheduler step, "
+                            f"batch {B} of 4x{LAT}x{LAT} latents + 77x768 context per GPU "
+                            + ("(BASELINE.json configs[1])" if headline else "(non-headline shape)"))
+            out = {
+                "metric": f"UNet denoise img-steps/sec at {LAT}x{LAT} latents",
+                "value": round(total * args.steps / elapsed, 2), "unit": "img-steps/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+                "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": workload, "per_gpu_batch": B, "global_batch": total, "latent": f"4x{LAT}x{LAT}",
+                           "parallelism": f"batch-sharded x{world}, no data-path collective",
+                           "end_to_end_tflops_per_gpu": round(flops_per_image * total / world / (elapsed / args.steps) / 1e12, 1),
+                           "end_to_end_frac_of_mfma_peak": round(flops_per_image * total / world / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
+                           "gemm_kernel_share_of_step": round(share, 3)},
+                "roofline": roof}
+            if world == 1 and not args.no_cpu_baseline and LAT == 64 and not args.strong:
+                out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
-        ms = 1e3 * elapsed / args.steps
-        value = world * B * args.steps / elapsed
-        # dominant kernel from the live event log
-        per = {}
-        for name, flops, e0, e1, _shape in log:
-            d = per.setdefault(name, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += flops
-            d[2] += e0.elapsed_time(e1) * 1e-3
-        gemm_time = sum(d[2] for d in per.values())
-        dom = max(per, key=lambda k: per[k][2])
-        n_l, fl, tt = per[dom]
-        achieved = fl / tt
-        # HBM bytes per launch of the dominant kernel: not measurable from inside the process; the figure is the one the
-        # separate rocprofv3 --pmc passes over this same command gave (FETCH_SIZE, doubled per the gfx950 correction, +
-        # WRITE_SIZE; profiles/r1_v10_pmc_per_kernel.md), reported only for the shape it was measured on.
-        pmc_traffic = {"conv_gemm_bf16_kernel<256,160,64>": 288.2e6}
-        traffic = pmc_traffic.get(dom) if (LAT == 64 and B == BATCH) else None
-        out = {
-            "metric": f"UNet denoise img-steps/sec at {LAT}x{LAT} latents",
-            "value": round(value, 2), "unit": "img-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SD-1.5-shaped UNet (859.5M params, random init) bf16 forward + DDPM scheduler step, "
-                                   f"batch {B} of 4x{LAT}x{LAT} latents + 77x768 context per GPU "
-                                   + ("(BASELINE.json configs[1])" if LAT == 64 and B == BATCH else "(non-headline shape)"),
-                       "per_gpu_batch": B, "global_batch": B * world, "latent": f"4x{LAT}x{LAT}",
-                       "parallelism": f"batch-sharded x{world}, no data-path collective",
-                       "end_to_end_tflops_per_gpu": round(flops_per_image * B / (elapsed / args.steps) / 1e12, 1),
-                       "end_to_end_frac_of_mfma_peak": round(flops_per_image * B / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
-                       "gemm_kernel_share_of_step": round(gemm_time / elapsed, 3)},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": traffic,
-                         "traffic_note": "HBM+Infinity-Cache bytes per launch from committed PMC passes "
-                                         "(profiles/r1_v10_pmc_per_kernel.md), not collected live",
-                         "launches": n_l, "avg_launch_us": round(1e6 * tt / n_l, 1),
-                         "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 2),
-                         "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
-                                                  "avg_us": round(1e6 * v[2] / v[0], 1)} for k, v in sorted(per.items())}},
-        }
-        if world == 1 and not args.no_cpu_baseline and LAT == 64:
-            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -79,7 +79,8 @@ int ldm_ddpm_step_cfg(const void* eps_u, const void* eps_c, int eps_dtype, float
 
 /* x_t = sqrt_acp[t_b]*x0 + sqrt(1-acp)[t_b]*noise, per-sample int64 t (DEVICE), tables DEVICE float32.
  * x0/noise share `dtype`; out is float32 (the float32 (B,1,1,1) coefficients promote the result).
- * batch samples of per_sample elements each.
+ * batch samples of per_sample elements each.  A timestep outside [0, T) -- a device assert in the reference's gather --
+ * yields NaN for that whole sample (the table read itself is clamped, so it cannot fault).
  * Replaces DDPMScheduler.add_noise + extract (scheduling_ddpm.py:81-101, :285-305). */
 int ldm_ddpm_add_noise(const void* x0, const void* noise, float* out, int dtype, const int64_t* t,
                        const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
@@ -162,7 +163,11 @@ typedef struct LdmConvGemm {
   int64_t workspace_bytes;
 } LdmConvGemm;
 
-/* out = epilogue(im2col(A) @ W^T).  M = batch*hout*wout rows.  Replaces nn.Conv2d 3x3/1x1 and nn.Linear
+/* Dropout (unet.py:636-639, :707, :579: nn.Dropout(p) after the attention output projection, inside ResnetBlock.layers and the
+ * feed-forward) has no kernel here: the reference's trainer and every default leave p = 0.0, where it is the identity; the
+ * Python drop-in raises NotImplementedError for dropout > 0 instead of silently ignoring it.
+ *
+ * out = epilogue(im2col(A) @ W^T).  M = batch*hout*wout rows.  Replaces nn.Conv2d 3x3/1x1 and nn.Linear
  * as called from ResnetBlock (unet.py:698-731), TransformerModel (:508,:521), Attention (:655-656,:683),
  * GEGLU (:787-790), feed_forward (:579), down/upsample (:218,:317), time_embedding (:29-33). */
 int ldm_conv_gemm(const LdmConvGemm* desc, void* stream);

@@ -212,8 +212,12 @@ ddpm_add_noise_kernel(const T* __restrict__ x0, const T* __restrict__ noise, flo
                       int T_steps, int64_t per_sample, int vec_ok) {
   const int b = blockIdx.y;
   int64_t tb = t[b];
-  tb = tb < 0 ? 0 : (tb >= T_steps ? T_steps - 1 : tb);  // host validated; clamp keeps a bad index from faulting
-  const float a = sa[tb], s = so[tb];
+  // A timestep outside [0, T) makes the reference's gather fail with a device assert (scheduling_ddpm.py:301).  Here the
+  // index is clamped so that the table read cannot fault and the sample's whole output is poisoned with NaN: a bad timestep
+  // must not come back as plausible noisy latents.
+  const bool bad_t = tb < 0 || tb >= T_steps;
+  tb = tb < 0 ? 0 : (tb >= T_steps ? T_steps - 1 : tb);
+  const float a = bad_t ? __builtin_nanf("") : sa[tb], s = bad_t ? __builtin_nanf("") : so[tb];
   const T* xb = x0 + (int64_t)b * per_sample;
   const T* nb = noise + (int64_t)b * per_sample;
   float* ob = out + (int64_t)b * per_sample;
@@ -250,8 +254,9 @@ train_input_prep_kernel(const float* __restrict__ moments, const float* __restri
                         float* __restrict__ noisy) {
   const int b = blockIdx.y;
   int64_t tb = t[b];
+  const bool bad_t = tb < 0 || tb >= T_steps;             // as in ddpm_add_noise_kernel: NaN-poisoned, never silently clamped
   tb = tb < 0 ? 0 : (tb >= T_steps ? T_steps - 1 : tb);
-  const float a = sa[tb], s = so[tb];
+  const float a = bad_t ? __builtin_nanf("") : sa[tb], s = bad_t ? __builtin_nanf("") : so[tb];
   const int64_t per_sample = (int64_t)channels * hw;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {

@@ -362,7 +362,7 @@ def unet_train(T: Tape, net, sample, t_f32, ctx, need_dsample: bool):
             if attns is not None:
                 h = transformer(f"down_blocks.{i}.attentions.{j}", attns[j], h)
             push_skip(h)
-        if hasattr(blk, "downsample"):
+        if getattr(blk, "downsample", None) is not None:
             h = conv(f"down_blocks.{i}.downsample", h, stride=2)
             push_skip(h)
     mid = net.mid_block
@@ -375,7 +375,7 @@ def unet_train(T: Tape, net, sample, t_f32, ctx, need_dsample: bool):
             h = resnet(f"up_blocks.{i}.resnets.{j}", r, h, skips.pop())
             if attns is not None:
                 h = transformer(f"up_blocks.{i}.attentions.{j}", attns[j], h)
-        if hasattr(blk, "upsample"):
+        if getattr(blk, "upsample", None) is not None:
             h = conv(f"up_blocks.{i}.upsample", h, upsample=True)
     hf = h
     a, stf = ops.groupnorm_with_stats(hf, P["final_conv.0.g"], P["final_conv.0.b"], g, silu=True)

@@ -62,6 +62,10 @@ class GraphedUNet:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = self._forward()
+            # The graph holds raw device pointers into the packed (derived) filters and no tensor references.  Keep the
+            # dict alive here: a training-form forward evicts the inference set from the module's cache
+            # (UNet._packed_for(train=True)) without changing any parameter, and a replay would then read freed memory.
+            self._packed = self.net._packed_for(self.compute_dtype)
         self._versions = self._param_versions()
 
     def __call__(self, sample: torch.Tensor, timestep, encoder_hidden_states: torch.Tensor) -> torch.Tensor:

@@ -247,8 +247,18 @@ def conv_wgrad(a0: torch.Tensor, dy: torch.Tensor, *, a1: Optional[torch.Tensor]
     need = lib.ldm_conv_wgrad_workspace_bytes(C.byref(d))
     ws = _wgrad_workspace(a0.device, need)
     with torch.cuda.device(a0.device):
-        _lib.check(lib.ldm_conv_wgrad(C.byref(d), dy.data_ptr(), out.data_ptr(), 1 if accumulate else 0, ws.data_ptr(),
-                                      ws.numel() * 4, _stream(a0)), "ldm_conv_wgrad")
+        if _launch_log is None:
+            _lib.check(lib.ldm_conv_wgrad(C.byref(d), dy.data_ptr(), out.data_ptr(), 1 if accumulate else 0, ws.data_ptr(),
+                                          ws.numel() * 4, _stream(a0)), "ldm_conv_wgrad")
+        else:  # bench.py --train: bracket the launch (kernel + fold) with HIP events on its stream
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.ldm_conv_wgrad(C.byref(d), dy.data_ptr(), out.data_ptr(), 1 if accumulate else 0, ws.data_ptr(),
+                                          ws.numel() * 4, _stream(a0)), "ldm_conv_wgrad")
+            e1.record()
+            m, k = batch * hout * wout, ksize * ksize * (c0 + c1)
+            _launch_log.append((f"conv_wgrad_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel(+fold)", 2.0 * m * n * k, e0, e1,
+                                (m, n, k, ksize, stride, int(bool(upsample)), c1, 0)))
     return out
 
 

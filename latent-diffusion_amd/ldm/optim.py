@@ -56,11 +56,33 @@ class _TensorTables:
         return table
 
 
+def _dense(t: torch.Tensor) -> bool:
+    """Non-overlapping and dense: the elements fill one gap-free run of storage in SOME dimension order (contiguous,
+    channels_last -- what ``module.to(memory_format=torch.channels_last)``, train_latent_diffusion.py:876, makes of every
+    3x3 filter --, a flat bucket slice, ...).  The multi-tensor kernels are elementwise over raw storage, so that is all
+    they need, provided parameter, gradient and optimizer state of one tensor share their strides."""
+    if t.is_contiguous():
+        return True
+    expect = 1
+    for stride, size in sorted((st, sz) for sz, st in zip(t.shape, t.stride()) if sz != 1):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
 def _check_f32(tensors, what):
     for t in tensors:
-        if t.dtype != torch.float32 or not t.is_contiguous():
-            raise TypeError(f"ldm_amd.optim: {what} must be contiguous float32 tensors (the trainer's master weights)")
+        if t.dtype != torch.float32 or not _dense(t):
+            raise TypeError(f"ldm_amd.optim: {what} must be dense (non-overlapping) float32 tensors (the trainer's master weights)")
     _gpu(*tensors)
+
+
+def _like_param(p: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """``t`` with the strides of ``p`` (a copy only when they differ: a contiguous gradient of a channels_last filter)."""
+    if t.stride() == p.stride() or t.numel() <= 1:
+        return t
+    return torch.empty_like(p, memory_format=torch.preserve_format).copy_(t)
 
 
 def clip_grad_norm_(parameters, max_norm: float) -> torch.Tensor:
@@ -113,13 +135,16 @@ class FusedAdamW(torch.optim.Optimizer):
             if not ps:
                 continue
             _check_f32(ps, "parameters")
-            _check_f32([p.grad for p in ps], "gradients")
             for p in ps:
+                if p.grad.dtype != torch.float32:
+                    raise TypeError("ldm_amd.optim: gradients must be float32 (the trainer's master weights)")
                 st = self.state[p]
                 if not st:
                     st["step"] = torch.zeros((), dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                for k in ("exp_avg", "exp_avg_sq"):      # a loaded state dict may carry another layout
+                    st[k] = _like_param(p, st[k])
             groups.append((gi, group, ps))
         if not groups:
             return loss
@@ -128,8 +153,11 @@ class FusedAdamW(torch.optim.Optimizer):
         gp_all = None
         with torch.cuda.device(dev):
             stream = _stream(groups[0][2][0])
+            # gradients as the update kernel reads them: the parameter's own strides (elementwise over raw storage)
+            gview = {p: _like_param(p, p.grad) for _, _, ps in groups for p in ps}
+            _gpu(*gview.values())
             if self.max_grad_norm is not None:      # one norm over every group, as clip_grad_norm_(model.parameters()) does
-                allg = [p.grad for _, _, ps in groups for p in ps]
+                allg = [gview[p] for _, _, ps in groups for p in ps]
                 tabs = self._tables_for("norm", tuple(g.numel() for g in allg), dev)
                 gp = _TensorTables.pointers(allg, dev)
                 gp_all = gp if len(groups) == 1 else None
@@ -148,7 +176,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
                 tabs = self._tables_for(gi, tuple(p.numel() for p in ps), dev)
                 pp = _TensorTables.pointers(ps, dev, (id(self), gi, "p"))
-                gp = gp_all if gp_all is not None else _TensorTables.pointers([p.grad for p in ps], dev)
+                gp = gp_all if gp_all is not None else _TensorTables.pointers([gview[p] for p in ps], dev)
                 mp = _TensorTables.pointers([self.state[p]["exp_avg"] for p in ps], dev, (id(self), gi, "m"))
                 vp = _TensorTables.pointers([self.state[p]["exp_avg_sq"] for p in ps], dev, (id(self), gi, "v"))
                 b1, b2 = group["betas"]

@@ -27,6 +27,36 @@ import torch.distributed as dist
 from torch import nn
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _host_staged(group) -> bool:
+    """gloo cannot move device memory on this platform (its CUDA-tensor collectives never complete on ROCm): device tensors
+    take a synchronous round trip through host memory.  Rehearsal path only -- several ranks sharing one GPU, CPU-only
+    launches; RCCL ("nccl"), the backend of record, reduces device memory in place, asynchronously."""
+    return dist.get_backend(group) != "nccl"
+
+
+def _all_reduce(t: torch.Tensor, op, group):
+    if t.is_cuda and _host_staged(group):
+        host = t.cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+        return _Done()
+    return dist.all_reduce(t, op=op, group=group, async_op=True)
+
+
+def _broadcast(t: torch.Tensor, src: int, group):
+    if t.is_cuda and _host_staged(group):
+        host = t.cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+    else:
+        dist.broadcast(t, src=src, group=group)
+
+
 class GradReducer:
     """Flat-bucket gradient averaging across a process group, fed in gradient-arrival order.
 
@@ -34,10 +64,15 @@ class GradReducer:
     every rank: the schedule is deterministic), like DDP's bucket rebuild; that first pass reduces bucket by bucket at
     the end, later passes overlap."""
 
-    def __init__(self, params: Dict[str, torch.Tensor], process_group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, params: Dict[str, torch.Tensor], process_group=None, bucket_bytes: int = 64 << 20,
+                 always_reduce: bool = False):
         self.params = params                      # name -> nn.Parameter
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # always_reduce: launch the collectives also in a group of ONE rank (an identity).  For tests and rehearsals: a
+        # one-GPU box then drives the real RCCL path -- async all-reduce of bucket views on RCCL's stream while the
+        # backward kernels keep running, handle waits at the end -- which world == 1 otherwise skips.
+        self.always_reduce = bool(always_reduce) and dist.is_initialized()
         self.bucket_bytes = int(bucket_bytes)
         self.order: List[str] = []                # arrival order (first pass)
         self.slot: Dict[str, tuple] = {}          # name -> (bucket index, offset, numel)
@@ -126,14 +161,14 @@ class GradReducer:
         """Average bucket ``bi`` over the group.  RCCL averages in the collective; backends without AVG (gloo) sum and
         the bucket is scaled when the pass finishes."""
         self.launched += 1
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             op = dist.ReduceOp.SUM
             if not prescaled:
                 if dist.get_backend(self.group) == "nccl":
                     op = dist.ReduceOp.AVG
                 else:
                     self._post_scale.append(bi)
-            self.handles.append(dist.all_reduce(self.buckets[bi], op=op, group=self.group, async_op=True))
+            self.handles.append(_all_reduce(self.buckets[bi], op, self.group))
 
     def finish(self) -> Dict[str, torch.Tensor]:
         """Completes the pass: after this the tensors returned by put() hold the averaged gradients (stream-ordered on
@@ -155,8 +190,8 @@ class GradReducer:
                     self._launch(bi)
             for name in sorted(self.pending):      # strays (see put): one small collective each, same order everywhere
                 self.launched += 1
-                if self.world > 1:
-                    self.handles.append(dist.all_reduce(self.pending[name], group=self.group, async_op=True))
+                if self.world > 1 or self.always_reduce:
+                    self.handles.append(_all_reduce(self.pending[name], dist.ReduceOp.SUM, self.group))
             self.pending = {}
         for h in self.handles:
             h.wait()
@@ -171,16 +206,16 @@ class DataParallel(nn.Module):
     """Drop-in for the DDP wrap accelerate applies to the UNet: ``DataParallel(unet)(sample, t, ctx)``; gradients in
     ``unet.parameters()`` after ``loss.backward()`` are the average over the process group."""
 
-    def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 64.0):
+    def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 64.0, always_reduce: bool = False):
         super().__init__()
         self.module = module
-        self.reducer = GradReducer(dict(module.named_parameters()), process_group, int(bucket_mb * (1 << 20)))
+        self.reducer = GradReducer(dict(module.named_parameters()), process_group, int(bucket_mb * (1 << 20)),
+                                   always_reduce=always_reduce)
         self.require_sync = True
         if dist.is_initialized() and dist.get_world_size(process_group) > 1:
             with torch.no_grad():                  # replicas start from rank 0's weights, as DDP's constructor does
                 for p in module.parameters():
-                    dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                                   group=process_group)
+                    _broadcast(p.data, dist.get_global_rank(process_group, 0) if process_group else 0, process_group)
 
     @contextlib.contextmanager
     def no_sync(self):

@@ -115,9 +115,10 @@ def generate_images(denoiser: Callable, scheduler, vae, ctx: torch.Tensor, **kw)
     return decode_images(vae, sample_latents(denoiser, scheduler, ctx, **kw))
 
 
-def gather_latents(local: torch.Tensor, n: int, rank: int, world: int, group=None) -> torch.Tensor:
-    """All-gather the shards back into the (n, ...) batch (the only collective of the sampling path, after the loop)."""
-    if world == 1:
+def gather_latents(local: torch.Tensor, n: int, rank: int, world: int, group=None, force: bool = False) -> torch.Tensor:
+    """All-gather the shards back into the (n, ...) batch (the only collective of the sampling path, after the loop).
+    force: run the collective also in a group of one rank (tests: drives RCCL on a one-GPU box)."""
+    if world == 1 and not force:
         return local
     import torch.distributed as dist
     sizes = [shard_range(n, r, world) for r in range(world)]

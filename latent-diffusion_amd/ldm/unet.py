@@ -102,8 +102,8 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
             if getattr(mod, "_ldm_raw", False):       # conv_in / final conv keep float32 OIHW filters
                 P[name + ".w"] = f32(mod.weight)
                 P[name + ".b"] = f32(mod.bias)
-            elif getattr(mod, "_ldm_skip", False):    # covered by a fused filter below
-                continue
+            elif getattr(mod, "_ldm_skip", False) or (getattr(mod, "_ldm_skip_in_unet", False) and isinstance(root, UNet)):
+                continue                              # covered by a fused filter below
             elif isinstance(mod, (nn.Conv2d, nn.Linear)):
                 glu = name.endswith("w1_w2")
                 if train:
@@ -169,6 +169,16 @@ class _HipModule(nn.Module):
                 cache.pop((dtype, False))      # the training set contains the inference set
             cache[key] = pack_tree(self, dtype, train)
         return cache[key]
+
+    def to(self, *args, **kwargs):
+        """``nn.Module.to`` minus ``memory_format``: the reference trainer moves the UNet to channels_last
+        (train_latent_diffusion.py:876) so that cuDNN runs NHWC; here every kernel already reads NHWC activations and derived
+        K-contiguous filters (``pack_tree``), so the parameters keep the checkpoint's layout -- re-striding them would only
+        add a copy per filter per step (pack, gradient, optimizer).  Shapes, values and ``state_dict()`` are unaffected."""
+        kwargs.pop("memory_format", None)
+        if not args and not kwargs:
+            return self
+        return super().to(*args, **kwargs)
 
     def invalidate_packed_weights(self):
         """Drop the derived filters (after writing parameters in a way torch cannot see)."""
@@ -406,8 +416,166 @@ class TransformerModel(_HipModule):
         return _to_nchw(out), (lambda dout: (_to_nchw(b(_to_nhwc(dout, dt))), T.dctx)), T
 
 
-class _Stage(nn.Module):
-    """Parameter container for one down / mid / up stage (resnets, attentions, downsample / upsample)."""
+def get_time_embed(sample: torch.Tensor, timestep: Union[torch.Tensor, float, int], num_channels: int) -> torch.Tensor:
+    """unet.py:159-174: sinusoidal embedding (cos first, frequency divisor num_channels/2 - 1) of a python int / float, a
+    0-d tensor or a (B,) tensor, expanded to the batch of ``sample`` and cast to its dtype.  (B, num_channels)."""
+    t = timestep
+    if not torch.is_tensor(t):
+        t = torch.tensor([t], dtype=torch.float64 if isinstance(t, float) else torch.int64)
+    elif t.dim() == 0:
+        t = t[None]
+    t = t.to(sample.device, non_blocking=True).expand(sample.shape[0]).to(torch.float32)
+    if sample.dtype in (torch.float32, torch.bfloat16):
+        return ops.timestep_embedding(t, num_channels, sample.dtype)
+    return ops.timestep_embedding(t, num_channels, torch.float32).to(sample.dtype)
+
+
+class _Stage(_HipModule):
+    """One down / mid / up stage of the UNet: the reference's block classes (unet.py:177-448) hold ``resnets``,
+    ``attentions`` and a ``downsample`` / ``upsample`` conv under exactly these names.  Inside ``UNet.forward`` the stages
+    are walked by the fused schedule (``_infer_steps`` / ``_train.unet_train``); called on their own (the reference's
+    ``forward`` signatures, NCHW tensors in and out) they run the same kernels block by block.  Stand-alone calls are
+    inference-only: gradients flow through ``UNet`` (or through ResnetBlock / TransformerModel called directly)."""
+
+    def _begin(self, hidden_states, temb, *others):
+        if self._check_call(hidden_states, temb, *others):
+            raise NotImplementedError("ldm_amd: a UNet stage called on its own is inference-only; wrap the call in "
+                                      "torch.no_grad() or differentiate through UNet / ResnetBlock / TransformerModel")
+        dt = compute_dtype_of(hidden_states)
+        P = self._packed_for(dt)
+        e = None if temb is None else ops.silu(temb.to(dt))     # nn.SiLU in front of every ResnetBlock.time (unet.py:703)
+        return dt, P, e
+
+    def _resnet(self, P, j, h, skip, e):
+        n = f"resnets.{j}"
+        rowvec = ops.conv_gemm(e, P[n + ".time.1.w"], bias=P[n + ".time.1.b"])
+        return run_resnet(P, n, self.resnets[j], h, skip, rowvec)
+
+    def _attn(self, P, j, h, ctx):
+        return run_transformer_model(P, f"attentions.{j}", self.attentions[j], h, ctx)
+
+
+def _resnets(chans, temb_channels, groups, dropout):
+    return nn.ModuleList([ResnetBlock(ci, co, temb_channels, groups, dropout) for ci, co in chans])
+
+
+def _transformers(n, c, heads, layers, cross_dim, dropout, groups, ff_mult, act):
+    return nn.ModuleList([TransformerModel(c, heads, layers, cross_dim, dropout, groups, ff_mult, act) for _ in range(n)])
+
+
+class CrossAttnDownBlock(_Stage):
+    """unet.py:177-237.  forward -> (hidden_states, (after layer 0, ..., after the stride-2 conv))."""
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 2,
+                 transformer_layers_per_block: int = 1, norm_num_groups: int = 32, num_attention_heads: int = 8,
+                 cross_attention_dim: int = 1280, feed_forward_mult: int = 4, activation_fn: str = "geglu"):
+        super().__init__()
+        self.resnets = _resnets([(in_channels if i == 0 else out_channels, out_channels) for i in range(num_layers)],
+                                temb_channels, norm_num_groups, dropout)
+        self.attentions = _transformers(num_layers, out_channels, num_attention_heads, transformer_layers_per_block,
+                                        cross_attention_dim, dropout, norm_num_groups, feed_forward_mult, activation_fn)
+        self.downsample = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=True)
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None):
+        dt, P, e = self._begin(hidden_states, temb, encoder_hidden_states)
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        h = _to_nhwc(hidden_states, dt)
+        states = ()
+        for j in range(len(self.resnets)):
+            h = self._attn(P, j, self._resnet(P, j, h, None, e), ctx)
+            states += (_to_nchw(h),)
+        h = ops.conv_gemm(h, P["downsample.w"], ksize=3, stride=2, bias=P["downsample.b"])
+        out = _to_nchw(h)
+        return out, states + (out,)
+
+
+class DownBlock(_Stage):
+    """unet.py:240-273."""
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 1,
+                 norm_num_groups: int = 32):
+        super().__init__()
+        self.resnets = _resnets([(in_channels if i == 0 else out_channels, out_channels) for i in range(num_layers)],
+                                temb_channels, norm_num_groups, dropout)
+
+    def forward(self, hidden_states, temb=None):
+        dt, P, e = self._begin(hidden_states, temb)
+        h = _to_nhwc(hidden_states, dt)
+        states = ()
+        for j in range(len(self.resnets)):
+            h = self._resnet(P, j, h, None, e)
+            states += (_to_nchw(h),)
+        return states[-1], states
+
+
+def _up_resnet_channels(in_channels, out_channels, final_skip_channels, num_layers):
+    return [((in_channels if i == 0 else out_channels) + (final_skip_channels if i == num_layers - 1 else out_channels),
+             out_channels) for i in range(num_layers)]
+
+
+class UpBlock(_Stage):
+    """unet.py:276-318: layer i reads cat([hidden, res_hidden_states_tuple[-i]]) -- here without materialising the concat --
+    then nearest-2x upsampling folded into the 3x3 conv's gather."""
+
+    def __init__(self, in_channels: int, out_channels: int, final_skip_channels: int, temb_channels: int, dropout: float = 0.0,
+                 num_layers: int = 1, norm_num_groups: int = 32):
+        super().__init__()
+        self.resnets = _resnets(_up_resnet_channels(in_channels, out_channels, final_skip_channels, num_layers),
+                                temb_channels, norm_num_groups, dropout)
+        self.upsample = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True)
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None):
+        dt, P, e = self._begin(hidden_states, temb, *res_hidden_states_tuple)
+        h = _to_nhwc(hidden_states, dt)
+        for j in range(len(self.resnets)):
+            h = self._resnet(P, j, h, _to_nhwc(res_hidden_states_tuple[-(j + 1)], dt), e)
+        return _to_nchw(ops.conv_gemm(h, P["upsample.w"], ksize=3, upsample=True, bias=P["upsample.b"]))
+
+
+class CrossAttnUpBlock(_Stage):
+    """unet.py:321-387."""
+
+    def __init__(self, in_channels: int, out_channels: int, final_skip_channels: int, temb_channels: int, dropout: float = 0.0,
+                 num_layers: int = 1, transformer_layers_per_block: int = 1, norm_num_groups: int = 32,
+                 num_attention_heads: int = 8, cross_attention_dim: int = 1280, feed_forward_mult: int = 4,
+                 activation_fn: str = "geglu", add_upsample: bool = True):
+        super().__init__()
+        self.resnets = _resnets(_up_resnet_channels(in_channels, out_channels, final_skip_channels, num_layers),
+                                temb_channels, norm_num_groups, dropout)
+        self.attentions = _transformers(num_layers, out_channels, num_attention_heads, transformer_layers_per_block,
+                                        cross_attention_dim, dropout, norm_num_groups, feed_forward_mult, activation_fn)
+        self.upsample = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=True) if add_upsample else None
+
+    def forward(self, hidden_states, res_hidden_states_tuple, temb=None, encoder_hidden_states=None):
+        dt, P, e = self._begin(hidden_states, temb, encoder_hidden_states, *res_hidden_states_tuple)
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        h = _to_nhwc(hidden_states, dt)
+        for j in range(len(self.resnets)):
+            h = self._attn(P, j, self._resnet(P, j, h, _to_nhwc(res_hidden_states_tuple[-(j + 1)], dt), e), ctx)
+        if self.upsample is not None:
+            h = ops.conv_gemm(h, P["upsample.w"], ksize=3, upsample=True, bias=P["upsample.b"])
+        return _to_nchw(h)
+
+
+class CrossAttnBlock(_Stage):
+    """unet.py:390-448 (the mid block): resnet, then (transformer, resnet) pairs."""
+
+    def __init__(self, in_channels: int, out_channels: int, temb_channels: int, dropout: float = 0.0, num_layers: int = 1,
+                 transformer_layers_per_block: int = 1, norm_num_groups: int = 32, num_attention_heads: int = 8,
+                 cross_attention_dim: int = 1280, feed_forward_mult: int = 4, activation_fn: str = "geglu"):
+        super().__init__()
+        self.resnets = _resnets([(in_channels if i == 0 else out_channels, out_channels) for i in range(num_layers + 1)],
+                                temb_channels, norm_num_groups, dropout)
+        self.attentions = _transformers(num_layers, out_channels, num_attention_heads, transformer_layers_per_block,
+                                        cross_attention_dim, dropout, norm_num_groups, feed_forward_mult, activation_fn)
+
+    def forward(self, hidden_states, temb=None, encoder_hidden_states=None):
+        dt, P, e = self._begin(hidden_states, temb, encoder_hidden_states)
+        ctx = encoder_hidden_states.to(dt).contiguous()
+        h = self._resnet(P, 0, _to_nhwc(hidden_states, dt), None, e)
+        for j in range(len(self.attentions)):
+            h = self._resnet(P, j + 1, self._attn(P, j, h, ctx), None, e)
+        return _to_nchw(h)
 
 
 _DONE = object()
@@ -445,51 +613,37 @@ class UNet(_HipModule):
         temb = ch[0] * 4
         n = len(ch)
 
-        def res(cin, cout):
-            return ResnetBlock(cin, cout, temb, g, dropout)
-
-        def tf(c):
-            return TransformerModel(c, num_attention_heads, transformer_layers_per_block, cross_attention_dim, dropout, g,
-                                    feed_forward_mult, activation_fn)
-
+        attn_kw = dict(transformer_layers_per_block=transformer_layers_per_block, norm_num_groups=g,
+                       num_attention_heads=num_attention_heads, cross_attention_dim=cross_attention_dim,
+                       feed_forward_mult=feed_forward_mult, activation_fn=activation_fn)
         self.conv_in = nn.Conv2d(in_channels, ch[0], 3, padding=1)
         self.conv_in._ldm_raw = True
         self.time_embedding = _seq(nn.Linear(ch[0], temb), nn.Identity(), nn.Linear(temb, temb))
         downs = []
-        for i in range(n):
+        for i in range(n):      # unet.py:35-62: the last down stage has neither attention nor a downsampler
             cin = ch[0] if i == 0 else ch[i - 1]
-            blk = _Stage()
-            blk.resnets = nn.ModuleList([res(cin if j == 0 else ch[i], ch[i]) for j in range(layers_per_block)])
-            if i < n - 1:  # the last down stage has neither attention nor a downsampler (unet.py:38-46)
-                blk.attentions = nn.ModuleList([tf(ch[i]) for _ in range(layers_per_block)])
-                blk.downsample = nn.Conv2d(ch[i], ch[i], 3, stride=2, padding=1)
-            downs.append(blk)
+            if i == n - 1:
+                downs.append(DownBlock(cin, ch[i], temb, dropout, layers_per_block, g))
+            else:
+                downs.append(CrossAttnDownBlock(cin, ch[i], temb, dropout, layers_per_block, **attn_kw))
         self.down_blocks = nn.ModuleList(downs)
-        mid = _Stage()
-        mid.resnets = nn.ModuleList([res(ch[-1], ch[-1]) for _ in range(2)])
-        mid.attentions = nn.ModuleList([tf(ch[-1])])
-        self.mid_block = mid
+        self.mid_block = CrossAttnBlock(ch[-1], ch[-1], temb, dropout, 1, **attn_kw)      # unet.py:63-75
         ups = []
-        for i in range(n):
+        for i in range(n):      # unet.py:77-111
             rev = n - 1 - i
             cin = ch[-1] if i == 0 else ch[rev + 1]
-            cout = ch[rev]
             last_skip = ch[0] if rev == 0 else ch[rev - 1]
-            L = layers_per_block + 1
-            blk = _Stage()
-            blk.resnets = nn.ModuleList([res((cin if j == 0 else cout) + (last_skip if j == L - 1 else cout), cout)
-                                         for j in range(L)])
-            if i > 0:
-                blk.attentions = nn.ModuleList([tf(cout) for _ in range(L)])
-            if i < n - 1:
-                blk.upsample = nn.Conv2d(cout, cout, 3, padding=1)
-            ups.append(blk)
+            if i == 0:
+                ups.append(UpBlock(cin, ch[rev], last_skip, temb, dropout, layers_per_block + 1, g))
+            else:
+                ups.append(CrossAttnUpBlock(cin, ch[rev], last_skip, temb, dropout, layers_per_block + 1,
+                                            add_upsample=i < n - 1, **attn_kw))
         self.up_blocks = nn.ModuleList(ups)
         self.final_conv = _seq(nn.GroupNorm(g, ch[0]), nn.Identity(), nn.Conv2d(ch[0], in_channels, 3, padding=1))
         self.final_conv[2]._ldm_raw = True
         for m in self.modules():  # the per-block time projections run as one fused GEMM
             if isinstance(m, ResnetBlock):
-                m.time[1]._ldm_skip = True
+                m.time[1]._ldm_skip_in_unet = True
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
                 encoder_hidden_states: torch.Tensor) -> torch.Tensor:
@@ -586,7 +740,7 @@ class UNet(_HipModule):
                     h = run_transformer_model(P, f"down_blocks.{i}.attentions.{j}", attns[j], h, ctx)
                     yield
                 skips.append(h)
-            if hasattr(blk, "downsample"):
+            if getattr(blk, "downsample", None) is not None:
                 nm = f"down_blocks.{i}.downsample"
                 h = ops.conv_gemm(h, P[nm + ".w"], ksize=3, stride=2, bias=P[nm + ".b"])
                 skips.append(h)
@@ -603,7 +757,7 @@ class UNet(_HipModule):
                 if attns is not None:
                     h = run_transformer_model(P, f"up_blocks.{i}.attentions.{j}", attns[j], h, ctx)
                     yield
-            if hasattr(blk, "upsample"):
+            if getattr(blk, "upsample", None) is not None:
                 nm = f"up_blocks.{i}.upsample"
                 h = ops.conv_gemm(h, P[nm + ".w"], ksize=3, upsample=True, bias=P[nm + ".b"])
         h = ops.groupnorm(h, P["final_conv.0.g"], P["final_conv.0.b"], self.norm_num_groups, silu=True)

@@ -150,3 +150,74 @@ def test_packed_weights_follow_every_optimizer(make):
         y2 = fresh(x, 10, ctx)
     assert not torch.equal(y0, y1)
     assert torch.equal(y1, y2)
+
+
+def test_channels_last_module_trains_with_every_optimizer():
+    """The reference trainer calls diffusion_model.to(memory_format=torch.channels_last) (train_latent_diffusion.py:876)
+    before building the optimizer.  One train step after that call with torch AdamW, FusedAdamW and FusedAdamW over
+    DataParallel's bucket-view gradients must equal the same step on a module that was never re-laid; and FusedAdamW /
+    clip_grad_norm_ on genuinely channels_last parameters and gradients (dense, non-contiguous) must match torch."""
+    from ldm.optim import FusedAdamW, clip_grad_norm_
+    from ldm.parallel import DataParallel
+    from ldm.unet import UNet
+    from oracle import unet_ref as uref
+    kw = dict(block_out_channels=[32, 64, 64, 64])
+    sd = uref.fill_state_dict(uref.param_shapes(uref.UNetConfig(**kw)), seed=7, gain=1.0)
+    x, ctx = seeded((2, 4, 16, 16), 11).cuda(), seeded((2, 77, 768), 12).cuda()
+    t = torch.tensor([17, 801], device="cuda")
+    noise = seeded((2, 4, 16, 16), 30).cuda()
+
+    def one_step(make_opt, channels_last, wrap=False):
+        net = UNet(**kw)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        if channels_last:
+            net = net.to(memory_format=torch.channels_last)
+        model = DataParallel(net) if wrap else net
+        opt = make_opt(net.parameters())
+        F.mse_loss(model(x, t, ctx).float(), noise).backward()
+        if not isinstance(opt, FusedAdamW):
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        return torch.cat([p.detach().flatten() for p in net.parameters()])
+
+    adamw = lambda p: torch.optim.AdamW(p, lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    fused = lambda p: FusedAdamW(p, lr=1e-4, max_grad_norm=1.0)
+    base = one_step(adamw, False)
+    assert torch.equal(one_step(adamw, True), base)
+    f0 = one_step(fused, False)
+    assert rel_l2(f0, base) < 2e-5
+    assert torch.equal(one_step(fused, True), f0)
+    assert torch.equal(one_step(fused, True, wrap=True), f0)
+
+    # dense, non-contiguous tensors through the multi-tensor kernels
+    shapes = [(64, 32, 3, 3), (48, 16, 3, 3), (40,), (24, 8, 1, 1)]
+    ps, qs = [], []
+    for i, shp in enumerate(shapes):
+        v = seeded(shp, 70 + i).cuda()
+        if len(shp) == 4:
+            v = v.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(v.clone(memory_format=torch.preserve_format)))
+        qs.append(torch.nn.Parameter(v.clone(memory_format=torch.preserve_format)))
+    assert not ps[0].is_contiguous()
+    of, ot = FusedAdamW(ps, lr=1e-4, max_grad_norm=1.0), adamw(qs)
+    for it in range(3):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            g = seeded(tuple(p.shape), 90 + 10 * it + i).cuda() * 2.0
+            # gradient layouts a trainer can produce: the parameter's own strides, or plain contiguous
+            p.grad = g.contiguous(memory_format=torch.channels_last) if (p.dim() == 4 and it % 2 == 0) else g.clone()
+            q.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        of.step()
+        ot.step()
+    for p, q in zip(ps, qs):
+        assert p.stride() == q.stride() and rel_l2(p, q) < 1e-6
+    for p, q in zip(ps, qs):
+        p.grad = q.grad = None
+        g = seeded(tuple(p.shape), 300).cuda() * 5
+        p.grad = g.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else g.clone()
+        q.grad = g.clone()
+    n, n_ref = clip_grad_norm_(ps, 1.0), torch.nn.utils.clip_grad_norm_(qs, 1.0)
+    assert abs(float(n) - float(n_ref)) < 1e-5 * float(n_ref)
+    for p, q in zip(ps, qs):
+        assert rel_l2(p.grad, q.grad) < 1e-6

@@ -155,6 +155,13 @@ def test_add_noise(golden, sched):
         assert outb.dtype == refb.dtype == torch.float32 and same_bits(outb, refb), shape
     with pytest.raises(ValueError):
         sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), torch.zeros(3, dtype=torch.long, device="cuda"))
+    # a timestep outside [0, T) (the reference's gather asserts on the device): that sample comes back as NaN, the others intact
+    tbad = g["add_noise.t"].clone()
+    tbad[1], tbad[3] = 1000, -1
+    outb = sched.add_noise(g["x_t"].cuda(), g["noise"].cuda(), tbad.cuda())
+    assert torch.isnan(outb[1]).all() and torch.isnan(outb[3]).all()
+    good = sref.add_noise(tabs, g["x_t"], g["noise"], g["add_noise.t"])
+    assert same_bits(outb[0], good[0]) and same_bits(outb[2], good[2])
 
 
 def test_fused_training_input_prep_matches_the_reference_sequence():

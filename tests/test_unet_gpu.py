@@ -515,3 +515,83 @@ def test_trajectory_bf16_psnr_floor(golden):
           f"HIP bf16 {pb:.1f} dB (torch bf16 {float(g['traj.psnr_torch_bf16']):.1f}, floor {floor_b:.1f})")
     assert p32 > 100.0
     assert pb > floor_b
+
+
+def test_stage_classes_stand_alone(golden):
+    """The reference's block classes (unet.py:177-448) called on their own, with the reference's forward signatures: float32
+    kernels against the oracle's composition of the same sub-blocks (1e-4), bf16 against 2e-2; get_time_embed (:159-174)."""
+    from ldm import unet as U
+    cfg = uref.UNetConfig(block_out_channels=[32, 64, 64, 64])
+    full = uref.fill_state_dict(uref.param_shapes(cfg), seed=7, gain=1.0)
+
+    def load(mod, prefix):
+        sd = {k[len(prefix) + 1:]: v for k, v in full.items() if k.startswith(prefix + ".")}
+        mod.load_state_dict(sd)
+        return mod.cuda().eval(), {f"{prefix}.{k}": v for k, v in sd.items()}
+
+    kw = dict(num_attention_heads=8, cross_attention_dim=768)
+    temb, ctx = seeded((2, 128), 301), seeded((2, 77, 768), 302)
+
+    def res(sd, p, x):
+        return uref.resnet_block(sd, p, x, temb, 32)
+
+    def tm(sd, p, x):
+        return uref.transformer_model(sd, p, x, ctx, cfg)
+
+    def both(fn_mod, ref):
+        with torch.no_grad():
+            y32 = fn_mod(torch.float32)
+            yb = fn_mod(torch.bfloat16)
+        y32 = y32 if isinstance(y32, tuple) else (y32,)
+        yb = yb if isinstance(yb, tuple) else (yb,)
+        ref = ref if isinstance(ref, tuple) else (ref,)
+        for a, b, r in zip(y32, yb, ref):
+            assert a.shape == r.shape and rel_l2(a, r) < 1e-4 and rel_l2(b, r) < 2e-2
+
+    c = lambda t, dt: t.cuda().to(dt)
+    # CrossAttnDownBlock: 32 -> 64 at 16x16 -> 8x8
+    m, sd = load(U.CrossAttnDownBlock(32, 64, 128, num_layers=2, **kw), "down_blocks.1")
+    x = seeded((2, 32, 16, 16), 303)
+    h0 = tm(sd, "down_blocks.1.attentions.0", res(sd, "down_blocks.1.resnets.0", x))
+    h1 = tm(sd, "down_blocks.1.attentions.1", res(sd, "down_blocks.1.resnets.1", h0))
+    h2 = uref._conv(sd, "down_blocks.1.downsample", h1, stride=2)
+    with torch.no_grad():
+        out = m(c(x, torch.float32), c(temb, torch.float32), c(ctx, torch.float32))
+    assert isinstance(out, tuple) and len(out[1]) == 3 and torch.equal(out[0], out[1][-1])
+    both(lambda dt: m(c(x, dt), c(temb, dt), c(ctx, dt))[1], (h0, h1, h2))
+    # DownBlock
+    m, sd = load(U.DownBlock(64, 64, 128, num_layers=2), "down_blocks.3")
+    x = seeded((2, 64, 4, 4), 304)
+    r0 = res(sd, "down_blocks.3.resnets.0", x)
+    r1 = res(sd, "down_blocks.3.resnets.1", r0)
+    both(lambda dt: m(c(x, dt), c(temb, dt))[1], (r0, r1))
+    # CrossAttnBlock (mid)
+    m, sd = load(U.CrossAttnBlock(64, 64, 128, num_layers=1, **kw), "mid_block")
+    ref = res(sd, "mid_block.resnets.1", tm(sd, "mid_block.attentions.0", res(sd, "mid_block.resnets.0", x)))
+    both(lambda dt: m(c(x, dt), c(temb, dt), c(ctx, dt)), ref)
+    # UpBlock: three resnets on cat([h, skip]) taken from the END of the tuple, then nearest-2x + conv
+    m, sd = load(U.UpBlock(64, 64, 64, 128, num_layers=3), "up_blocks.0")
+    skips = tuple(seeded((2, 64, 4, 4), 310 + i) for i in range(3))
+    h = x
+    for j in range(3):
+        h = res(sd, f"up_blocks.0.resnets.{j}", torch.cat([h, skips[-(j + 1)]], dim=1))
+    ref = uref._conv(sd, "up_blocks.0.upsample", torch.nn.functional.interpolate(h, scale_factor=2.0, mode="nearest"))
+    both(lambda dt: m(c(x, dt), tuple(c(s, dt) for s in skips), c(temb, dt)), ref)
+    # CrossAttnUpBlock without upsampler (the last up stage): 64 -> 32, final skip 32
+    m, sd = load(U.CrossAttnUpBlock(64, 32, 32, 128, num_layers=3, add_upsample=False, **kw), "up_blocks.3")
+    x = seeded((2, 64, 8, 8), 320)
+    skips = (seeded((2, 32, 8, 8), 321), seeded((2, 32, 8, 8), 322), seeded((2, 32, 8, 8), 323))
+    h = x
+    for j in range(3):
+        h = res(sd, f"up_blocks.3.resnets.{j}", torch.cat([h, skips[-(j + 1)]], dim=1))
+        h = tm(sd, f"up_blocks.3.attentions.{j}", h)
+    both(lambda dt: m(c(x, dt), tuple(c(s, dt) for s in skips), c(temb, dt), c(ctx, dt)), h)
+    with pytest.raises(NotImplementedError):
+        m(x.cuda().requires_grad_(True), tuple(s.cuda() for s in skips), temb.cuda(), ctx.cuda())
+    # get_time_embed: python int / float, 0-d and (B,) tensors; result in the sample's dtype
+    smp = torch.zeros(3, 4, 8, 8, device="cuda")
+    for t in (37, 37.5, torch.tensor(980), torch.tensor([1, 500, 999])):
+        e = U.get_time_embed(smp, t, 320)
+        ref = uref.timestep_embedding(uref.expand_timestep(t, 3), 320)
+        assert e.shape == (3, 320) and e.dtype == torch.float32 and (e.cpu() - ref).abs().max() < 3e-4
+    assert U.get_time_embed(smp.bfloat16(), 5, 320).dtype == torch.bfloat16
