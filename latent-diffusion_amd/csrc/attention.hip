@@ -456,6 +456,10 @@ attention_generic_kernel(const AttnParams p, int d) {
   }
 }
 
+// attention32.hip: the 32x32x16, software-pipelined kernel for small head dims (d = 40); true when it took the call
+bool attention32_try(const void* q, int q_stride, const void* k, const void* v, int kv_stride, void* out, int out_stride,
+                     int batch, int heads, int lq, int lk, int d, float scale_log2e, float* lse, hipStream_t st, int* rc);
+
 template <int D>
 static int launch_mfma(const AttnParams& p, hipStream_t st) {
   using G = AttnGeom<D>;
@@ -524,6 +528,10 @@ static int attention_impl(const void* q, int q_stride, const void* k, const void
   const bool vec_ok = aligned16(q) && aligned16(k) && aligned16(v) && (reinterpret_cast<uintptr_t>(out) & 7) == 0 &&
                       q_stride % 8 == 0 && kv_stride % 8 == 0 && out_stride % 4 == 0;
   if (dtype == LDM_BF16 && vec_ok && (long long)lk * kv_stride * 2 < (1LL << 31)) {
+    static const bool v1 = getenv("LDM_ATTN_V1") != nullptr;      // tools/attention_bench.py: the 16x16x32 kernel for d = 40 (A/B)
+    int rc = LDM_OK;
+    if (!v1 && attention32_try(q, q_stride, k, v, kv_stride, out, out_stride, batch, heads, lq, lk, d, p.scale_log2e, lse, st, &rc))
+      return rc;
     switch (d) {
       case 40: return launch_mfma<40>(p, st);
       case 64: return launch_mfma<64>(p, st);

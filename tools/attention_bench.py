@@ -1,5 +1,5 @@
 """Timing of the attention kernel on the UNet's shapes (B=32).  LDM_AMD_LIB=<other .so> runs another build (A/B).
-Usage: python tools/attention_bench.py [--iters N]"""
+Usage: python tools/attention_bench.py [--iters N] [--only "L0 self"]"""
 import os
 import sys
 
@@ -17,10 +17,13 @@ CASES = [("L0 self 4096x4096 d40", 32, 4096, 4096, 8, 40), ("L1 self 1024x1024 d
 
 def main():
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None      # substring of a case name
     dev = torch.device("cuda")
     g = torch.Generator(device=dev).manual_seed(0)
     print("library:", os.environ.get("LDM_AMD_LIB", "default"))
     for name, B, lq, lk, H, d in CASES:
+        if only is not None and only not in name:
+            continue
         q = torch.randn(B, lq, H * d, device=dev, generator=g).bfloat16()
         kv = torch.randn(B, lk, 2 * H * d, device=dev, generator=g).bfloat16()
         for _ in range(3):
