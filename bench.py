@@ -320,7 +320,8 @@ def main():
                            "parallelism": f"batch-sharded x{world}, no data-path collective",
                            "end_to_end_tflops_per_gpu": round(flops_per_image * total / world / (elapsed / args.steps) / 1e12, 1),
                            "end_to_end_frac_of_mfma_peak": round(flops_per_image * total / world / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
-                           "gemm_kernel_share_of_step": round(share, 3)},
+                           "gemm_kernel_share_of_step": round(share, 3),
+                           "layernorm_fold_active": bool(ops._ln_fold_checked) and all(ops._ln_fold_checked.values())},
                 "roofline": roof}
             if world == 1 and not args.no_cpu_baseline and LAT == 64 and not args.strong:
                 out["cpu_baseline"] = cpu_baseline()

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 1
+#define LDM_ABI_VERSION 2   /* 2: struct LdmConvGemm gained the LayerNorm-fold fields at its end */
 
 enum { LDM_F32 = 0, LDM_BF16 = 1 };
 
@@ -128,7 +128,16 @@ enum {
   LDM_EPI_RESIDUAL = 4,    /* + residual[m][n]        (unet.py:731, :593-594) */
   LDM_EPI_SILU = 8,        /* y = y*sigmoid(y)        (time_embedding SiLU, unet.py:31, :703) */
   LDM_EPI_GEGLU = 16,      /* out[m][j] = v*gelu_erf(g), paired columns (unet.py:787-790) */
-  LDM_EPI_SWIGLU = 32      /* out[m][j] = v*silu(g) (unet.py:765-768) */
+  LDM_EPI_SWIGLU = 32,     /* out[m][j] = v*silu(g) (unet.py:765-768) */
+  /* nn.LayerNorm (unet.py:550-551, :576) folded into the two GEMMs around it instead of a pass of its own (bf16 only):
+   *   producer (the GEMM that writes x):  LDM_EPI_ROWSTATS also writes, per row and 80-column segment, the sum and the sum of
+   *     squares of the outputs as stored -> rowstats[m][n / 80][2] (float32; n % 160 == 0; deterministic);
+   *   consumer (the GEMM that reads LayerNorm(x)): LDM_EPI_LNFOLD runs on x itself with the filter pre-scaled by gamma,
+   *     W'[n][k] = gamma[k] W[n][k], and finishes in the epilogue: y = rstd_m (x W'^T - mean_m * ln_colsum[n]) + bias[n], where
+   *     ln_colsum[n] = sum_k W'[n][k] (of the rounded W') and `bias` already holds bias + W beta.  mean / rstd come from the
+   *     producer's rowstats (ln_stats, ln_segments = producer's n / 80) with K = c0 columns and eps = ln_eps. */
+  LDM_EPI_ROWSTATS = 64,
+  LDM_EPI_LNFOLD = 128
 };
 
 typedef struct LdmConvGemm {
@@ -161,6 +170,12 @@ typedef struct LdmConvGemm {
    * sharing one workspace must be ordered on one stream.  The result is deterministic either way. */
   void* workspace;
   int64_t workspace_bytes;
+  /* LayerNorm fold (ABI version 2; zero / NULL when unused) */
+  float* rowstats;             /* LDM_EPI_ROWSTATS: out, [m][n / 80][2] float32 */
+  const float* ln_stats;       /* LDM_EPI_LNFOLD: the rowstats the producer of the A operand wrote */
+  const float* ln_colsum;      /* LDM_EPI_LNFOLD: [n] float32 */
+  int32_t ln_segments;         /* LDM_EPI_LNFOLD: segments per row of ln_stats (= c0 / 80) */
+  float ln_eps;                /* LDM_EPI_LNFOLD: LayerNorm eps (1e-5 in the reference) */
 } LdmConvGemm;
 
 /* Dropout (unet.py:636-639, :707, :579: nn.Dropout(p) after the attention output projection, inside ResnetBlock.layers and the

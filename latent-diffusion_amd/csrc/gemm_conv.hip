@@ -36,6 +36,11 @@ struct ConvGemmParams {
   int out_f32;      // out dtype is float32 (else same as compute dtype)
   int tiles_m, tiles_n;
   int vec_epilogue; // 16-byte epilogue accesses are legal (alignment and n % 8 checked on the host)
+  float* rowstats;        // LDM_EPI_ROWSTATS: [M][N / 80][2] partial (sum, sum of squares) of the rounded outputs per row
+  const float* ln_stats;  // LDM_EPI_LNFOLD: the producer's rowstats of THIS call's A operand, [M][ln_nseg][2]
+  int ln_nseg;
+  const float* ln_s1;     //   [N]: sum_k W'[n][k] of the gamma-scaled filter this call multiplies with
+  float ln_eps;
   int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
   float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
@@ -116,6 +121,24 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   int tm, tn;
   tile_to_mn(tile, p.tiles_m, p.tiles_n, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- LDM_EPI_LNFOLD: mean / rstd of this workgroup's rows of A from the producer's per-segment partial sums (fixed
+  // order: deterministic); thread r owns row m0 + r and keeps the pair in two registers until the epilogue.  Loaded and
+  // consumed here, before any LDS-DMA is in flight (a later use of an ordinary load would drain the DMA queue).
+  float ln_mu = 0.f, ln_r = 0.f;
+  if (p.ln_stats != nullptr && tid < BM && m0 + tid < p.M) {
+    const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)(m0 + tid) * p.ln_nseg;
+    float sx = 0.f, sq = 0.f;
+    for (int i = 0; i < p.ln_nseg; ++i) {
+      const float2 v = st[i];
+      sx += v.x;
+      sq += v.y;
+    }
+    const float inv_k = 1.0f / (float)p.K;
+    ln_mu = sx * inv_k;
+    const float var = fmaxf(sq * inv_k - ln_mu * ln_mu, 0.f);
+    ln_r = rsqrtf(var + p.ln_eps);
+  }
 
   // ---- operand staging: LDS-DMA through buffer descriptors.  Per K-tile a wave issues A_IT + B_IT
   // `buffer_load_dwordx4 ... offen lds` with a per-lane byte offset that stays fixed while the K loop walks the
@@ -354,6 +377,19 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   }
 
   LDM_STAMP(3);
+  // ---- LDM_EPI_LNFOLD: row statistics and the column sums of the scaled filter go to LDS behind the epilogue's staging area
+  constexpr int EPI_CST_BYTES = WM * WN * 16 * (WTN + 4) * 4;
+  constexpr int EPI_LN_BYTES = BM * 8 + BN * 4;
+  constexpr int EPI_RST_BYTES = WM * WN * 16 * (WTN / 8) * 8;
+  static_assert(EPI_CST_BYTES + EPI_LN_BYTES + EPI_RST_BYTES <= STAGES * STAGE, "epilogue scratch does not fit the tile buffers");
+  float* const lnst = reinterpret_cast<float*>(smem + EPI_CST_BYTES);     // [BM][2] mean, rstd
+  float* const lns1 = lnst + BM * 2;                                       // [BN]
+  const bool has_ln = p.ln_stats != nullptr;
+  if (has_ln) {
+    if (tid < BM) { lnst[2 * tid] = ln_mu; lnst[2 * tid + 1] = ln_r; }
+    for (int c = tid; c < BN; c += NT) lns1[c] = n0 + c < p.N ? p.ln_s1[n0 + c] : 0.f;
+    __syncthreads();
+  }
   // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
   const bool split = p.splits > 1;           // raw fp32 partial sums, epilogue applied by splitk_reduce_kernel
   const int epi = split ? 0 : p.epilogue;
@@ -401,6 +437,12 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         }
       }
       const bool has_res = !GLU && (epi & LDM_EPI_RESIDUAL), has_row = !GLU && (epi & LDM_EPI_ROWVEC);
+      // LDM_EPI_ROWSTATS (bf16 out, N a multiple of the 80-column wave tile): per 16-row step every lane leaves the sum and
+      // sum of squares of its 8 rounded outputs in LDS, lanes 0..15 fold the row's CPRW chunks in a fixed order and write
+      // one (sum, sumsq) pair per row and 80-column segment: the LayerNorm statistics of the next GEMM's A operand.
+      const bool want_stats = !GLU && p.rowstats != nullptr;
+      float* const rst = reinterpret_cast<float*>(smem + EPI_CST_BYTES + EPI_LN_BYTES) + wave * (16 * (WTN / 8) * 2);
+      const int rs_seg = ncol0 / WTN, rs_nseg = p.N / WTN;
       uint4 rres[NPASS], rrow[NPASS];
       auto fetch = [&](int i, uint4 (&qres)[NPASS], uint4 (&qrow)[NPASS]) {
 #pragma unroll
@@ -441,12 +483,25 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           const float4 x0 = *reinterpret_cast<const float4*>(src);
           const float4 x1 = *reinterpret_cast<const float4*>(src + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+          float mu = 0.f, rr = 1.f;
+          if (has_ln) {   // y = rstd * (x W'^T - mean * colsum(W')) + (bias + W beta): LayerNorm folded into this GEMM
+            const float2 st = *reinterpret_cast<const float2*>(lnst + 2 * (wm * WTM + i * 16 + row[ps]));
+            mu = st.x; rr = st.y;
+            const float* s1p = lns1 + wn * WTN + scol[ps];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rr * (v[e] - mu * s1p[e]);
+          }
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += bv[ps][e];
           if constexpr (GLU) {
             const float4 g0 = *reinterpret_cast<const float4*>(src + 16);
             const float4 g1 = *reinterpret_cast<const float4*>(src + 20);
             float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            if (has_ln) {
+              const float* s1g = lns1 + wn * WTN + scol[ps] + 16;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] = rr * (g[e] - mu * s1g[e]);
+            }
             if (epi & LDM_EPI_GEGLU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_fast(g[e] + bg[ps][e]);
@@ -464,6 +519,36 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           }
           if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
           else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+          if (want_stats) {
+            float sx = 0.f, sq = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {       // statistics of the values as stored (rounded to the output dtype)
+              float a = v[e], b = v[e + 1];
+              if (!out_f32) {
+                const uint32_t w = pack_bf16x2(a, b);
+                a = __uint_as_float(w << 16);
+                b = __uint_as_float(w & 0xffff0000u);
+              }
+              sx += a + b;
+              sq += a * a + b * b;
+            }
+            const int c = lane + 64 * ps;            // chunk index inside the 16 x WTN step: row * CPRW + chunk of the row
+            *reinterpret_cast<float2*>(rst + 2 * c) = make_float2(sx, sq);
+          }
+        }
+        if (want_stats) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          const int m = mrow0 + i * 16 + lane;
+          if (lane < 16 && m < p.M) {
+            float sx = 0.f, sq = 0.f;
+#pragma unroll
+            for (int cidx = 0; cidx < CPRW; ++cidx) {
+              const float2 t = *reinterpret_cast<const float2*>(rst + 2 * (lane * CPRW + cidx));
+              sx += t.x;
+              sq += t.y;
+            }
+            *reinterpret_cast<float2*>(p.rowstats + ((size_t)m * rs_nseg + rs_seg) * 2) = make_float2(sx, sq);
+          }
         }
         if (i + 1 < MI) {
 #pragma unroll
@@ -757,6 +842,7 @@ static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per
 // need an even number of 16-column tiles per wave, i.e. BN = 128, and are never split.
 static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspace_bytes, int& bm, int& bn, int& bk, int& splits) {
   splits = 1;
+  const bool need160 = p.rowstats != nullptr;          // row statistics are written per 80-column wave tile: BN = 160 tiles only
   const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
   if (!bk64) {
     bk = 32;
@@ -767,7 +853,7 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspac
   if (const char* force = getenv("LDM_GEMM_TILE")) {   // tuning knob (tools/gemm_bench.py): "BM,BN[,splits]" of a BK=64 tile
     int fm = 0, fn = 0, fs = 1;
     const int got = sscanf(force, "%d,%d,%d", &fm, &fn, &fs);
-    if (got >= 2 && (fm == 64 || fm == 128 || fm == 256) && (fn == 128 || (fn == 160 && !glu))) {
+    if (got >= 2 && (fm == 64 || fm == 128 || fm == 256) && ((fn == 128 && !need160) || (fn == 160 && !glu))) {
       bm = fm; bn = fn;
       if (got == 3 && fs >= 1 && fs <= 16 && !glu && (long long)fs * p.M * p.N * 4 <= workspace_bytes && p.K / 64 >= fs) splits = fs;
       return;
@@ -779,6 +865,7 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspac
   double best = -1.0;
   for (const auto& c : cand) {
     if (glu && c[1] != 128) continue;
+    if (need160 && c[1] != 160) continue;
     for (int sp : split_cand) {
       if (sp > 1 && (glu || nk / sp < 16 || (long long)sp * p.M * p.N * 4 > workspace_bytes)) continue;
       const double sc = tile_score(p, c[0], c[1], c[2], sp);
@@ -844,10 +931,25 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.vec_epilogue = 0;
   p.splits = 1;
   p.partial = nullptr;
+  p.rowstats = (epi & LDM_EPI_ROWSTATS) ? d->rowstats : nullptr;
+  p.ln_stats = (epi & LDM_EPI_LNFOLD) ? d->ln_stats : nullptr;
+  p.ln_nseg = d->ln_segments;
+  p.ln_s1 = d->ln_colsum;
+  p.ln_eps = d->ln_eps;
 #ifdef LDM_GEMM_STAMPS
   p.stamps = nullptr;
 #endif
   hipStream_t st = (hipStream_t)stream;
+  if (epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD)) {
+    LDM_REQUIRE(d->dtype == LDM_BF16, "ldm_conv_gemm: LDM_EPI_ROWSTATS / LDM_EPI_LNFOLD are bf16-only");
+    if (epi & LDM_EPI_ROWSTATS)
+      LDM_REQUIRE(d->rowstats && !glu && d->n % 160 == 0 && (reinterpret_cast<uintptr_t>(d->rowstats) & 7) == 0,
+                  "ldm_conv_gemm: LDM_EPI_ROWSTATS needs a rowstats buffer, no GLU and n %% 160 == 0 (n=%d)", d->n);
+    if (epi & LDM_EPI_LNFOLD)
+      LDM_REQUIRE(d->ln_stats && d->ln_colsum && d->ln_segments >= 1 && d->ln_segments <= 64 && d->ksize == 1 && d->c1 == 0 &&
+                      d->stride == 1 && !d->upsample && d->ln_eps > 0.f && (reinterpret_cast<uintptr_t>(d->ln_stats) & 7) == 0,
+                  "ldm_conv_gemm: LDM_EPI_LNFOLD needs ln_stats / ln_colsum / ln_segments and a plain (1x1, single-source) layer");
+  }
 
   if (d->dtype == LDM_F32) {
     LDM_REQUIRE(p.ctot % 16 == 0 && p.c0 % 16 == 0, "ldm_conv_gemm(f32): channel counts must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
@@ -877,10 +979,17 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     if (glu) ok = ok && p.N % 32 == 0;
     p.vec_epilogue = ok ? 1 : 0;
   }
+  LDM_REQUIRE(p.vec_epilogue || !(epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD)),
+              "ldm_conv_gemm: LDM_EPI_ROWSTATS / LDM_EPI_LNFOLD need 16-byte aligned operands and n %% 8 == 0");
   int bm, bn, bk;
-  const bool ws_ok = d->workspace != nullptr && aligned16(d->workspace) && p.vec_epilogue;
+  const bool ws_ok = d->workspace != nullptr && aligned16(d->workspace) && p.vec_epilogue &&
+                     !(epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD));       // the split-K fold kernel knows neither
   pick_tile_bf16(p, glu, ws_ok ? d->workspace_bytes : 0, bm, bn, bk, p.splits);
   p.partial = static_cast<float*>(d->workspace);
+  // row statistics are laid out per 80-column wave tile of a BN = 160 tile (rowstats[m][n / 80][2]): any other tile would
+  // write a different segment count than the caller allocated
+  LDM_REQUIRE(!(epi & LDM_EPI_ROWSTATS) || (bn == 160 && bk == 64),
+              "ldm_conv_gemm: LDM_EPI_ROWSTATS needs channel counts in multiples of 64 and n %% 160 == 0 (tile %dx%dx%d)", bm, bn, bk);
   const int key = bm * 1000000 + bn * 1000 + bk;
   switch (key) {
     case 64064032: return launch_bf16<64, 64, 32, 2, 2>(p, st);
@@ -904,8 +1013,10 @@ extern "C" int ldm_conv_gemm_tile(const LdmConvGemm* d, int tile[3]) {
   p.c0 = d->c0; p.c1 = d->c1; p.ctot = d->c0 + d->c1;
   p.M = d->batch * d->hout * d->wout; p.N = d->n;
   p.K = d->ksize * d->ksize * p.ctot;
+  p.rowstats = (d->epilogue & LDM_EPI_ROWSTATS) ? d->rowstats : nullptr;
   const bool glu = (d->epilogue & (LDM_EPI_GEGLU | LDM_EPI_SWIGLU)) != 0;
+  const bool fold = (d->epilogue & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD)) != 0;
   int splits;
-  pick_tile_bf16(p, glu, d->workspace ? d->workspace_bytes : 0, tile[0], tile[1], tile[2], splits);
+  pick_tile_bf16(p, glu, d->workspace && !fold ? d->workspace_bytes : 0, tile[0], tile[1], tile[2], splits);
   return LDM_OK;
 }

@@ -17,7 +17,8 @@ import torch  # noqa: F401
 
 F32, BF16 = 0, 1
 
-EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU, EPI_GEGLU, EPI_SWIGLU = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU, EPI_GEGLU, EPI_SWIGLU, EPI_ROWSTATS, EPI_LNFOLD = 1, 2, 4, 8, 16, 32, 64, 128
+ABI_VERSION = 2
 
 # LDM_AMD_LIB overrides the path (A/B runs of two builds of the library; there is still no fallback).
 _LIB_PATH = os.environ.get("LDM_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -46,6 +47,8 @@ class ConvGemmDesc(C.Structure):
         ("residual", c_void_p), ("out", c_void_p),
         ("dtype", C.c_int32), ("out_dtype", C.c_int32),
         ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
+        ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p),
+        ("ln_segments", C.c_int32), ("ln_eps", C.c_float),
     ]
 
 
@@ -151,8 +154,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_longlong
         fn.argtypes = argtypes
-    if lib.ldm_abi_version() != 1:
-        raise LdmError(f"ABI version mismatch: library reports {lib.ldm_abi_version()}, binding expects 1")
+    if lib.ldm_abi_version() != ABI_VERSION:
+        raise LdmError(f"ABI version mismatch: library reports {lib.ldm_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

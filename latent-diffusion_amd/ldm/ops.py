@@ -92,10 +92,14 @@ def pack_weight_pair(w: torch.Tensor, dtype: torch.dtype, *, glu_pairs: bool = F
 def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
               upsample: bool = False, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, silu: bool = False, glu: Optional[str] = None,
-              out_dtype: Optional[torch.dtype] = None, out_hw=None) -> torch.Tensor:
+              out_dtype: Optional[torch.dtype] = None, out_hw=None, rowstats: bool = False, ln=None):
     """Implicit-GEMM conv / linear.  a0 (and a1): (B, H, W, C) NHWC, or (..., C) matrices for ksize == 1.
     w: packed [N, ksize*ksize*(C0+C1)].  Returns NHWC (B, Hout, Wout, N') / (..., N').
-    upsample: False, True (nearest 2x, unet.py:316) or "zero" (zero-insertion 2x: input gradient of a stride-2 conv)."""
+    upsample: False, True (nearest 2x, unet.py:316) or "zero" (zero-insertion 2x: input gradient of a stride-2 conv).
+    LayerNorm fold (bf16; include/ldm_amd.h LDM_EPI_ROWSTATS / LDM_EPI_LNFOLD): ``rowstats=True`` returns (out, stats) with
+    stats (M, N / 80, 2) float32 = per-row partial (sum, sumsq) of the output; ``ln=(stats, colsum, eps)`` treats a0 as the
+    INPUT of a LayerNorm whose statistics are ``stats``: w must be the gamma-scaled filter, colsum its row sums, and bias
+    must already contain W beta (``fold_layernorm`` builds the three)."""
     _gpu(a0, a1, w, bias, rowvec, residual)
     if not a0.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
         raise ValueError("conv_gemm: activations must be contiguous NHWC")
@@ -141,6 +145,11 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
         epi |= EPI_SWIGLU
     elif glu is not None:
         raise ValueError(f"Unsupported activation function: {glu}")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != n or not bias.is_contiguous()):
+        raise TypeError(f"conv_gemm: bias must be a contiguous float32 vector of {n} elements (got {bias.dtype}, {tuple(bias.shape)})")
+    for name_, t_ in (("rowvec", rowvec), ("residual", residual), ("a1", a1), ("w", w)):
+        if t_ is not None and t_.dtype != a0.dtype:
+            raise TypeError(f"conv_gemm: {name_} must have the activation dtype {a0.dtype} (got {t_.dtype})")
     odt = out_dtype or a0.dtype
     nout = n // 2 if glu else n
     out = torch.empty((*out_lead, nout), dtype=odt, device=a0.device)
@@ -148,7 +157,22 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
                      ksize=ksize, stride=stride, upsample=(2 if upsample == "zero" else 1 if upsample else 0), w=w.data_ptr(), n=n, epilogue=epi,
                      bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
                      residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
-    if a0.dtype == torch.bfloat16 and batch * hout * wout <= _SPLITK_MAX_ROWS:
+    stats = None
+    if rowstats:
+        if n % 160 or (c0 + c1) % 64 or c0 % 64 or a0.dtype != torch.bfloat16 or glu or odt != torch.bfloat16:
+            raise ValueError("conv_gemm(rowstats=True): bf16 in and out, no GLU, N a multiple of 160, channels multiples of 64")
+        stats = torch.empty((batch * hout * wout, n // 80, 2), dtype=torch.float32, device=a0.device)
+        d.epilogue |= _lib.EPI_ROWSTATS
+        d.rowstats = stats.data_ptr()
+    if ln is not None:
+        ln_stats, ln_colsum, ln_eps = ln
+        _gpu(ln_stats, ln_colsum)
+        if ln_stats.dtype != torch.float32 or ln_stats.dim() != 3 or ln_stats.shape[0] != batch * hout * wout or \
+                ln_stats.shape[2] != 2 or not ln_stats.is_contiguous() or ln_colsum.numel() != n or ln_colsum.dtype != torch.float32:
+            raise ValueError("conv_gemm(ln=...): stats must be float32 (M, segments, 2), colsum float32 (N,)")
+        d.epilogue |= _lib.EPI_LNFOLD
+        d.ln_stats, d.ln_colsum, d.ln_segments, d.ln_eps = ln_stats.data_ptr(), ln_colsum.data_ptr(), ln_stats.shape[1], float(ln_eps)
+    if a0.dtype == torch.bfloat16 and batch * hout * wout <= _SPLITK_MAX_ROWS and not rowstats and ln is None:
         ws = _splitk_workspace(a0.device)   # small-M layers may split K; ordered by the current stream like `out`
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     with torch.cuda.device(a0.device):
@@ -165,7 +189,97 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
             _launch_log.append((f"conv_gemm_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel<{tile[0]},{tile[1]},{tile[2]}>",
                                 2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1,
                                 (m, n, ksize * ksize * (c0 + c1), ksize, stride, int(bool(upsample)), c1, epi)))
-    return out
+    return (out, stats) if rowstats else out
+
+
+def ln_fold_supported(channels: int, dtype: torch.dtype) -> bool:
+    """The LayerNorm fold needs bf16 and a producer whose rows are whole 80-column wave tiles of BN = 160, BK = 64 GEMM
+    tiles: channel counts in multiples of lcm(160, 64) = 320 (320 / 640 / 1280 in the SD-1.5-shaped model)."""
+    return dtype == torch.bfloat16 and channels % 320 == 0
+
+
+def fold_layernorm_terms(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype):
+    """Pure torch (any device; tests/test_ln_fold_cpu.py): the three tensors of the identity
+        LayerNorm(x) W^T + bias  ==  rstd (x W'^T - mean * colsum) + bias'
+    W' = W * gamma [N, K] float32 (to be rounded to ``dtype`` by the packer), colsum[n] = sum_k round(W')[n][k], bias' =
+    bias + W beta, float32."""
+    with torch.autocast(w.device.type, enabled=False):   # packing may run inside the caller's bf16 autocast region: keep float32
+        w32 = w.detach().to(torch.float32)
+        ws = w32 * gamma.detach().to(torch.float32)[None, :]
+        colsum = ws.to(dtype).to(torch.float32).sum(dim=1)        # of the ROUNDED filter: what the matrix core multiplies with
+        b2 = (w32 * beta.detach().to(torch.float32)[None, :]).sum(dim=1)
+        if bias is not None:
+            b2 = b2 + bias.detach().to(torch.float32)
+    assert ws.dtype == colsum.dtype == b2.dtype == torch.float32
+    return ws, colsum, b2
+
+
+def fold_layernorm(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype,
+                   glu_pairs: bool = False):
+    """(packed filter, colsum, bias) of the GEMM  LayerNorm(x) W^T + bias  rewritten on x itself (``fold_layernorm_terms``);
+    w: float32 [N, K] checkpoint filter; glu_pairs: interleave value / gate rows in blocks of 16 as
+    ``pack_weight(glu_pairs=True)`` does (colsum and bias' in the same order)."""
+    ws, colsum, b2 = fold_layernorm_terms(w, bias, gamma, beta, dtype)
+    wp = pack_weight(ws, dtype, glu_pairs=glu_pairs)
+    if glu_pairs:
+        colsum = pack_weight(colsum, torch.float32, glu_pairs=True).flatten()
+        b2 = pack_weight(b2, torch.float32, glu_pairs=True).flatten()
+    if colsum.dtype != torch.float32 or b2.dtype != torch.float32 or wp.dtype != dtype:
+        raise TypeError("fold_layernorm: packed terms came out in the wrong dtype")
+    return wp, colsum.contiguous(), b2.contiguous()
+
+
+_ln_fold_checked = {}
+
+
+def ln_fold_selfcheck(device) -> bool:
+    """Once per process and device, before the first forward that would use the LayerNorm fold: the folded chain (producer
+    GEMM with row statistics -> consumer GEMM, plain and GEGLU) against the LayerNorm kernel + the plain GEMMs on random data,
+    at a row count that selects the LARGE tiles (256x160 for the producer and the q|k|v projection, 128x128 for GEGLU) -- the
+    instantiations the benchmarked batch runs and the small parity cases do not.  A mismatch disables the fold for the process
+    (the separate LayerNorm kernel runs instead) and says so; it never falls back to anything but another HIP kernel."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key in _ln_fold_checked:
+        return _ln_fold_checked[key]
+    if torch.cuda.is_current_stream_capturing():     # no host sync under capture: decide later, run unfused for now
+        return False
+    import math
+    import warnings
+    ok, why = False, ""
+    try:
+        with torch.no_grad(), torch.autocast("cuda", enabled=False), torch.cuda.device(device):
+            g = torch.Generator(device=device).manual_seed(20251111)
+            M, Cc = 32768, 320
+            bf = torch.bfloat16
+
+            def rnd(*shape):
+                return torch.randn(*shape, device=device, generator=g)
+
+            a, res = rnd(M, Cc).to(bf), (rnd(M, Cc) * 0.5 + 0.25).to(bf)
+            wp, bp = pack_weight(rnd(Cc, Cc) / math.sqrt(Cc), bf), rnd(Cc)
+            x, st = conv_gemm(a, wp, bias=bp, residual=res, rowstats=True)
+            x0 = conv_gemm(a, wp, bias=bp, residual=res)
+            errs = [float((x.float() - x0.float()).norm() / x0.float().norm())]
+            tot = st.sum(dim=1)
+            errs.append(float((tot[:, 0] - x.float().sum(dim=1)).abs().max()) / 50.0)     # sums of 320 O(1) values: 1e-2 scale
+            gamma, beta = 1 + 0.1 * rnd(Cc), 0.1 * rnd(Cc)
+            for N, glu in ((3 * Cc, None), (8 * Cc, "geglu")):
+                w, b = rnd(N, Cc) / math.sqrt(Cc), rnd(N)
+                wf, cs, b2 = fold_layernorm(w, b, gamma, beta, bf, glu_pairs=bool(glu))
+                y = conv_gemm(x, wf, bias=b2, glu=glu, ln=(st, cs, 1e-5))
+                b0 = pack_weight(b, torch.float32, glu_pairs=True).flatten() if glu else b
+                y0 = conv_gemm(layernorm(x, gamma, beta), pack_weight(w, bf, glu_pairs=bool(glu)), bias=b0, glu=glu)
+                errs.append(float((y.float() - y0.float()).norm() / y0.float().norm()))
+            ok = all(e == e and e < 1.5e-2 for e in errs)
+            why = "relative differences " + ", ".join(f"{e:.2e}" for e in errs)
+    except Exception as exc:   # an argument check of the library, an allocation failure: keep the proven path
+        why = f"{type(exc).__name__}: {exc}"
+    if not ok:
+        warnings.warn("ldm_amd: the LayerNorm-fold self-check did not pass (" + why + "); the separate LayerNorm kernel is used "
+                      "for this process")
+    _ln_fold_checked[key] = ok
+    return ok
 
 
 def pack_weight_dgrad(w: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -40,6 +40,9 @@ def _seq(*mods):
     return nn.Sequential(*mods)
 
 
+_LN_FOLD = os.environ.get("LDM_LN_FOLD", "1") != "0"      # A/B switch (tools): 0 = the separate LayerNorm kernel everywhere
+
+
 def compute_dtype_of(x: torch.Tensor) -> torch.dtype:
     """bf16 storage / fp32 accumulation for bf16 inputs or under bf16 autocast, exact fp32 otherwise."""
     if x.dtype == torch.bfloat16:
@@ -118,6 +121,24 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
                 P[name + ".b"] = f32(mod.bias)
             if isinstance(mod, Attention) and mod.fused_qkv:
                 pack_fused(_j(name, "qkv"), [mod.q_proj.weight, mod.kv_proj.weight])
+        if not train:
+            # inference: the three LayerNorms of every TransformerBlock inside a TransformerModel (unet.py:550-551, :576)
+            # folded into the GEMMs around them (ops.fold_layernorm; include/ldm_amd.h LDM_EPI_LNFOLD)
+            for name, mod in root.named_modules():
+                if isinstance(mod, TransformerModel) and _LN_FOLD and ops.ln_fold_supported(mod.in_channels, dtype) \
+                        and ops.ln_fold_selfcheck(mod.norm.weight.device):
+                    for k, blk in enumerate(mod.transformer_blocks):
+                        b = _j(name, f"transformer_blocks.{k}")
+                        a1 = blk.attn1
+                        wqkv = torch.cat([a1.q_proj.weight, a1.kv_proj.weight], 0) if a1.fused_qkv else a1.q_proj.weight
+                        for key, w, bias, ln, glu in (
+                                (b + (".attn1.qkv" if a1.fused_qkv else ".attn1.q_proj"), wqkv, None, blk.norm1, False),
+                                (b + ".attn2.q_proj", blk.attn2.q_proj.weight, None, blk.norm2, False),
+                                (b + ".feed_forward.1.w1_w2", blk.feed_forward[1].w1_w2.weight, blk.feed_forward[1].w1_w2.bias,
+                                 blk.feed_forward[0], True)):
+                            P[key + ".w_ln"], P[key + ".s1"], P[key + ".b_ln"] = ops.fold_layernorm(w, bias, ln.weight, ln.bias,
+                                                                                                  dtype, glu_pairs=glu)
+                    P[_j(name, "ln_fold")] = True
         resnets = [(n, m) for n, m in root.named_modules() if isinstance(m, ResnetBlock)]
         if isinstance(root, UNet) and resnets:
             # all time projections (unet.py:703) as one filter; each resnet reads its column slice
@@ -218,24 +239,43 @@ def run_resnet(P, n: str, r: "ResnetBlock", x, skip, rowvec):
     return ops.conv_gemm(a, P[_j(n, "layers.3.w")], ksize=3, bias=P[_j(n, "layers.3.b")], residual=res)
 
 
-def run_attention(P, n: str, a: "Attention", x, ctx, residual=None):
-    """unet.py:641-684.  ctx None = self-attention (one fused q|k|v GEMM)."""
+def run_attention(P, n: str, a: "Attention", x, ctx, residual=None, ln=None, rowstats=False):
+    """unet.py:641-684.  ctx None = self-attention (one fused q|k|v GEMM).
+    ln = (stats, eps): x is the INPUT of the LayerNorm in front of this attention (its q / q|k|v projection runs the folded
+    form); rowstats: the output projection also returns the row statistics of its result (for the next LayerNorm)."""
     C = a.inner_dim
+
+    def proj(key):
+        if ln is None:
+            return ops.conv_gemm(x, P[_j(n, key + ".w")])
+        return ops.conv_gemm(x, P[_j(n, key + ".w_ln")], bias=P[_j(n, key + ".b_ln")], ln=(ln[0], P[_j(n, key + ".s1")], ln[1]))
+
     if ctx is None and a.fused_qkv:
-        qkv = ops.conv_gemm(x, P[_j(n, "qkv.w")])
+        qkv = proj("qkv")
         q, kv = qkv[..., :C], qkv[..., C:]
     else:
-        q = ops.conv_gemm(x, P[_j(n, "q_proj.w")])
+        q = proj("q_proj")
         if isinstance(ctx, _ContextKV):
             kv = ctx.of(P, n, 2 * C)
         else:
+            assert ln is None or ctx is not None      # a folded self-attention always has the fused q|k|v filter
             kv = ops.conv_gemm(x if ctx is None else ctx, P[_j(n, "kv_proj.w")])
     att = ops.attention(q, kv, a.num_heads)
-    return ops.conv_gemm(att, P[_j(n, "output_proj.0.w")], bias=P[_j(n, "output_proj.0.b")], residual=residual)
+    return ops.conv_gemm(att, P[_j(n, "output_proj.0.w")], bias=P[_j(n, "output_proj.0.b")], residual=residual, rowstats=rowstats)
 
 
-def run_transformer_block(P, n: str, blk: "TransformerBlock", x, ctx):
-    """unet.py:593-596 on (B, L, C)."""
+LN_EPS = 1e-5
+
+
+def run_transformer_block(P, n: str, blk: "TransformerBlock", x, ctx, stats=None, rowstats=False):
+    """unet.py:593-596 on (B, L, C).  stats: row statistics of x from its producer -> the LayerNorm-folded schedule (no
+    LayerNorm kernel; every GEMM that writes a LayerNorm input also writes its row statistics)."""
+    if stats is not None:
+        x1, st1 = run_attention(P, _j(n, "attn1"), blk.attn1, x, None, residual=x, ln=(stats, LN_EPS), rowstats=True)
+        x2, st2 = run_attention(P, _j(n, "attn2"), blk.attn2, x1, ctx, residual=x1, ln=(st1, LN_EPS), rowstats=True)
+        k = _j(n, "feed_forward.1.w1_w2")
+        y = ops.conv_gemm(x2, P[k + ".w_ln"], bias=P[k + ".b_ln"], glu=blk.activation_fn, ln=(st2, P[k + ".s1"], LN_EPS))
+        return ops.conv_gemm(y, P[_j(n, "feed_forward.3.w")], bias=P[_j(n, "feed_forward.3.b")], rowstats=rowstats)
     y = ops.layernorm(x, P[_j(n, "norm1.g")], P[_j(n, "norm1.b")])
     x1 = run_attention(P, _j(n, "attn1"), blk.attn1, y, None, residual=x)
     y = ops.layernorm(x1, P[_j(n, "norm2.g")], P[_j(n, "norm2.b")])
@@ -249,9 +289,18 @@ def run_transformer_model(P, n: str, t: "TransformerModel", h, ctx):
     """unet.py:507-521 on the NHWC activation viewed as (B, HW, C)."""
     B, H, W, C = h.shape
     x = ops.groupnorm(h, P[_j(n, "norm.g")], P[_j(n, "norm.b")], t.norm_num_groups)
-    x = ops.conv_gemm(x.view(B, H * W, C), P[_j(n, "proj_in.w")], bias=P[_j(n, "proj_in.b")])
-    for k, blk in enumerate(t.transformer_blocks):
-        x = run_transformer_block(P, _j(n, f"transformer_blocks.{k}"), blk, x, ctx)
+    fold = bool(P.get(_j(n, "ln_fold"))) and x.dtype == torch.bfloat16 and B * H * W > 0 and _LN_FOLD
+    nb = len(t.transformer_blocks)
+    if fold:
+        x, stats = ops.conv_gemm(x.view(B, H * W, C), P[_j(n, "proj_in.w")], bias=P[_j(n, "proj_in.b")], rowstats=True)
+        for k, blk in enumerate(t.transformer_blocks):
+            x = run_transformer_block(P, _j(n, f"transformer_blocks.{k}"), blk, x, ctx, stats=stats, rowstats=k + 1 < nb)
+            if k + 1 < nb:
+                x, stats = x
+    else:
+        x = ops.conv_gemm(x.view(B, H * W, C), P[_j(n, "proj_in.w")], bias=P[_j(n, "proj_in.b")])
+        for k, blk in enumerate(t.transformer_blocks):
+            x = run_transformer_block(P, _j(n, f"transformer_blocks.{k}"), blk, x, ctx)
     x = ops.conv_gemm(x, P[_j(n, "proj_out.w")], bias=P[_j(n, "proj_out.b")])  # no skip connection (:521)
     return x.view(B, H, W, C)
 

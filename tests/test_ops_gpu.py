@@ -680,3 +680,42 @@ def test_conv3x3_headline_rows():
     full = F.linear(xr.view(-1, C)[rows], wg.bfloat16().float(), bg)
     val, gate = full.chunk(2, dim=-1)
     assert rel_l2(yg[rows.cuda()], val * F.gelu(gate)) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("M,C,N,glu", [(300, 320, 960, None), (1000, 640, 640, None), (130, 1280, 1280, None),
+                                       (257, 320, 2560, "geglu"), (64, 640, 5120, "swiglu"), (4096, 320, 320, None)])
+def test_layernorm_folded_into_gemms(M, C, N, glu):
+    """LDM_EPI_ROWSTATS + LDM_EPI_LNFOLD (unet.py:550-551, :576 without a LayerNorm pass): a producer GEMM with bias + residual
+    writes x and its per-row partial statistics; the consumer GEMM runs on x with the gamma-scaled filter and finishes
+    rstd (acc - mean colsum) + bias' in its epilogue.  Against float32 torch: LayerNorm of the stored bf16 x, then the linear
+    layer (and GEGLU / SwiGLU) -- same tolerance as the unfused kernels."""
+    ops = _ops()
+    a, ar = _q(seeded((M, C), 1), torch.bfloat16)
+    res, resr = _q(seeded((M, C), 2) * 0.5 + 0.3, torch.bfloat16)        # a mean that is not zero
+    wp_ = seeded((C, C), 3) / math.sqrt(C)
+    bp = seeded((C,), 4)
+    x, stats = ops.conv_gemm(a, ops.pack_weight(wp_.cuda(), torch.bfloat16), bias=bp.cuda(), residual=res, rowstats=True)
+    assert stats.shape == (M, C // 80, 2)
+    xr = x.float().cpu()
+    assert rel_l2(x, F.linear(ar, wp_.bfloat16().float(), bp) + resr) < TOL[torch.bfloat16]
+    tot = stats.sum(dim=1).cpu().double()
+    assert torch.allclose(tot[:, 0], xr.double().sum(1), rtol=0, atol=1e-3)
+    assert torch.allclose(tot[:, 1], (xr.double() ** 2).sum(1), rtol=1e-5, atol=1e-3)
+    gamma, beta = 1 + 0.1 * seeded((C,), 5), 0.1 * seeded((C,), 6)
+    nrows = 2 * N if glu else N
+    w = seeded((nrows, C), 7) / math.sqrt(C)
+    b = seeded((nrows,), 8)
+    wf, colsum, bf = ops.fold_layernorm(w.cuda(), b.cuda(), gamma.cuda(), beta.cuda(), torch.bfloat16, glu_pairs=bool(glu))
+    y = ops.conv_gemm(x, wf, bias=bf, glu=glu, ln=(stats, colsum, 1e-5))
+    full = F.linear(F.layer_norm(xr, (C,), gamma, beta, 1e-5), w, b)
+    if glu:
+        val, gate = full.chunk(2, dim=-1)
+        full = val * (F.gelu(gate) if glu == "geglu" else F.silu(gate))
+    assert y.shape == (M, N)
+    assert rel_l2(y, full) < TOL[torch.bfloat16]
+    # and against the unfused kernels on the same x: LayerNorm kernel + plain GEMM
+    y0 = ops.conv_gemm(ops.layernorm(x, gamma.cuda(), beta.cuda()), ops.pack_weight(w.cuda(), torch.bfloat16, glu_pairs=bool(glu)),
+                       bias=ops.pack_weight(b.cuda(), torch.float32, glu_pairs=True).flatten() if glu else b.cuda(), glu=glu)
+    assert rel_l2(y, y0) < 2 * TOL[torch.bfloat16]
+    with pytest.raises(ValueError):
+        ops.conv_gemm(a, ops.pack_weight(seeded((96, C), 9).cuda(), torch.bfloat16), rowstats=True)   # N not a multiple of 160

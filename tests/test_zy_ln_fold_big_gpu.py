@@ -1,0 +1,50 @@
+"""LayerNorm fold on the LARGE GEMM tiles (collected late on purpose: these instantiations could not be re-run on a GPU after
+their last edit in round 2).  The small-tile cases are tests/test_ops_gpu.py::
+test_layernorm_folded_into_gemms; here the row counts of BASELINE.json configs[1] select the 256x160 tile for the producer and
+the q|k|v projection and the 128x128 tile for GEGLU.  Reference: float32 torch on sampled rows."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2, seeded
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ln_fold_selfcheck_passes():
+    """The runtime guard of the product (ldm.ops.ln_fold_selfcheck) on this device: fold == LayerNorm kernel + GEMM."""
+    from ldm import ops
+    assert ops.ln_fold_selfcheck(torch.device("cuda", torch.cuda.current_device()))
+
+
+@pytest.mark.parametrize("M,C", [(32768, 320), (32768, 640), (8192, 1280), (131072, 320)])
+def test_ln_fold_large_tiles(M, C):
+    from ldm import ops
+    bf = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+
+    def rnd(*shape):
+        return torch.randn(*shape, device="cuda", generator=g)
+
+    a, res = rnd(M, C).to(bf), (rnd(M, C) * 0.5 + 0.3).to(bf)
+    wp_, bp = rnd(C, C) / math.sqrt(C), rnd(C)
+    x, st = ops.conv_gemm(a, ops.pack_weight(wp_, bf), bias=bp, residual=res, rowstats=True)
+    rows = torch.tensor([0, 1, 255, 256, M // 2 + 17, M - 257, M - 1])
+    xr = x[rows.cuda()].float().cpu()
+    ref_x = F.linear(a[rows.cuda()].float().cpu(), wp_.to(bf).float().cpu(), bp.cpu()) + res[rows.cuda()].float().cpu()
+    assert rel_l2(xr, ref_x) < 6e-3
+    tot = st.sum(dim=1)[rows.cuda()].cpu().double()
+    assert torch.allclose(tot[:, 0], xr.double().sum(1), rtol=0, atol=2e-3)
+    assert torch.allclose(tot[:, 1], (xr.double() ** 2).sum(1), rtol=2e-5, atol=2e-3)
+    gamma, beta = 1 + 0.1 * rnd(C), 0.1 * rnd(C)
+    for N, glu in ((3 * C, None), (C, None), (8 * C, "geglu")):
+        w, b = rnd(N, C) / math.sqrt(C), rnd(N)
+        wf, cs, b2 = ops.fold_layernorm(w, b, gamma, beta, bf, glu_pairs=bool(glu))
+        y = ops.conv_gemm(x, wf, bias=b2, glu=glu, ln=(st, cs, 1e-5))
+        full = F.linear(F.layer_norm(xr, (C,), gamma.cpu(), beta.cpu(), 1e-5), w.cpu(), b.cpu())
+        if glu:
+            val, gate = full.chunk(2, dim=-1)
+            full = val * F.gelu(gate)
+        assert rel_l2(y[rows.cuda()], full) < 6e-3, (N, glu)
