@@ -239,7 +239,7 @@ def ln_fold_selfcheck(device) -> bool:
     instantiations the benchmarked batch runs and the small parity cases do not.  A mismatch disables the fold for the process
     (the separate LayerNorm kernel runs instead) and says so; it never falls back to anything but another HIP kernel."""
     device = torch.device(device)
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    key = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else -1)
     if key in _ln_fold_checked:
         return _ln_fold_checked[key]
     if torch.cuda.is_current_stream_capturing():     # no host sync under capture: decide later, run unfused for now

@@ -58,3 +58,68 @@ def test_fold_support_predicate_and_validation():
     assert not ops.ln_fold_supported(320, torch.float32)
     for c in (32, 64, 160, 480):                     # not multiples of lcm(160, 64): unfused LayerNorm kernel
         assert not ops.ln_fold_supported(c, torch.bfloat16)
+
+
+# ------------------------------------------------------------------ the runtime self-check, executed against host emulations
+def _emu_pack_weight(w, dtype, glu_pairs=False):
+    w = w.detach().to(torch.float32)
+    flat = w.dim() == 1
+    if flat:
+        w = w[:, None]
+    if glu_pairs:      # value rows 16 b .. 16 b + 15, then their gate rows (include/ldm_amd.h ldm_pack_weight)
+        n = w.shape[0] // 2
+        w = torch.stack([w[:n].view(n // 16, 16, -1), w[n:].view(n // 16, 16, -1)], dim=1).reshape(2 * n, -1)
+    return w.to(dtype)
+
+
+def _emu_conv_gemm(a0, w, *, bias=None, residual=None, glu=None, rowstats=False, ln=None, **_):
+    acc = a0.float() @ w.float().t()
+    if ln is not None:
+        stats, colsum, eps = ln
+        K = a0.shape[-1]
+        mu = stats[..., 0].sum(1) / K
+        rstd = torch.rsqrt((stats[..., 1].sum(1) / K - mu * mu).clamp(min=0) + eps)
+        acc = rstd[:, None] * (acc - mu[:, None] * colsum[None, :])
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == w.shape[0]
+        acc = acc + bias[None, :]
+    if glu:
+        blocks = acc.view(acc.shape[0], -1, 2, 16)
+        val, gate = blocks[:, :, 0], blocks[:, :, 1]
+        acc = (val * (F.gelu(gate) if glu == "geglu" else F.silu(gate))).reshape(acc.shape[0], -1)
+    if residual is not None:
+        acc = acc + residual.float()
+    out = acc.to(a0.dtype)
+    if rowstats:
+        seg = out.float().view(out.shape[0], -1, 80)
+        return out, torch.stack([seg.sum(-1), (seg * seg).sum(-1)], dim=-1).contiguous()
+    return out
+
+
+def test_selfcheck_runs_and_detects_a_broken_fold(monkeypatch):
+    """ops.ln_fold_selfcheck line by line on the host: pack_weight / conv_gemm / layernorm replaced by torch emulations of
+    what the kernels compute (including the GLU row interleave of filter, colsum and bias).  A correct fold passes; a fold
+    whose column sums are wrong is detected, disabled and reported with a warning."""
+    import contextlib
+    import warnings
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.cuda, "device", lambda d: contextlib.nullcontext())
+    monkeypatch.setattr(ops, "pack_weight", _emu_pack_weight)
+    monkeypatch.setattr(ops, "conv_gemm", _emu_conv_gemm)
+    monkeypatch.setattr(ops, "layernorm", lambda x, g, b, eps=1e-5: F.layer_norm(x.float(), x.shape[-1:], g, b, eps).to(x.dtype))
+    monkeypatch.setattr(ops, "_ln_fold_checked", {})
+    cpu = torch.device("cpu")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")           # a passing check must not warn
+        assert ops.ln_fold_selfcheck(cpu) is True
+    assert ops.ln_fold_selfcheck(cpu) is True      # cached
+
+    def broken(a0, w, **kw):
+        if kw.get("ln") is not None:
+            st, cs, eps = kw["ln"]
+            kw["ln"] = (st, cs * 1.5, eps)
+        return _emu_conv_gemm(a0, w, **kw)
+    monkeypatch.setattr(ops, "conv_gemm", broken)
+    monkeypatch.setattr(ops, "_ln_fold_checked", {})
+    with pytest.warns(UserWarning, match="self-check did not pass"):
+        assert ops.ln_fold_selfcheck(cpu) is False
