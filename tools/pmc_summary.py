@@ -23,6 +23,12 @@ def short(name):
     return s[:60]
 
 
+def full_name(k):
+    """bench.py's spelling of a GEMM kernel: conv_gemm_bf16_kernel<BM,BN,BK> (the trace has the wave layout and stage count too)."""
+    m = re.match(r"(conv_gemm_(?:bf16|f32)_kernel)<(\d+), ?(\d+), ?(\d+)", k)
+    return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>" if m else k
+
+
 def load(path):
     per = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum
     calls = defaultdict(set)
@@ -42,7 +48,10 @@ def load(path):
 
 def main():
     d = sys.argv[1]
-    fwd = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    fwd = int(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else 3
+    json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None      # bench_pmc_traffic.json
+    workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "fwd_b32_l64"
+    profile = sys.argv[sys.argv.index("--profile") + 1] if "--profile" in sys.argv else d
     sq, calls, dur = load(os.path.join(d, "sq_counter_collection.csv"))
     fe, _, fdur = load(os.path.join(d, "fetch_counter_collection.csv"))
     wr, _, wdur = load(os.path.join(d, "write_counter_collection.csv"))
@@ -67,6 +76,17 @@ def main():
     for t, k, n, util, wany, winst, act, clk, rd, wb, bw in rows:
         print(f"| `{k}` | {n / fwd:.0f} | {t / fwd * 1e3:.3f} | {100 * util:.1f}% | {100 * wany:.0f}% | {100 * winst:.0f}% | "
               f"{100 * act:.0f}% | {clk:.2f} | {rd / n / 1e6:.1f} | {wb / n / 1e6:.1f} | {bw:.0f} |")
+    if json_out:
+        # what bench.py's roofline.traffic reads: HBM(+Infinity Cache) bytes per launch per kernel, valid for the kernel sources
+        # that were profiled (hash of latent-diffusion_amd/csrc, as bench.kernel_source_hash computes it)
+        import json
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from bench import kernel_source_hash
+        rec = {"source_hash": kernel_source_hash(), "profile": profile,
+               "workloads": {workload: {full_name(k): {"hbm_bytes_per_launch": (rd + wb) / n, "launches_per_forward": n / fwd}
+                                        for t, k, n, util, wany, winst, act, clk, rd, wb, bw in rows if n}}}
+        with open(json_out, "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
