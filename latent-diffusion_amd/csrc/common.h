@@ -8,6 +8,13 @@
 
 #include "../../include/ldm_amd.h"
 
+// Marks a point where the lanes of ONE wave hand data to each other through LDS and rely on the wave executing in lockstep
+// (the hardware needs no instruction there).  Expands to nothing; the host emulator of the test suite (tests/emu), whose
+// lanes are fibers, turns it into a wave rendezvous.
+#ifndef LDM_LOCKSTEP
+#define LDM_LOCKSTEP() do {} while (0)
+#endif
+
 namespace ldm {
 
 // ----------------------------------------------------------------------------- error plumbing

@@ -554,6 +554,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
 #pragma unroll
           for (int ps = 0; ps < NPASS; ++ps) { rres[ps] = nres[ps]; rrow[ps] = nrow[ps]; }
         }
+        LDM_LOCKSTEP();   // the next step overwrites the staging rows other lanes have just read
       }
     };
     if (glu) {

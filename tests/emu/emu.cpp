@@ -1,0 +1,413 @@
+// Host-side SIMT emulator: scheduler, cross-lane operations, LDS-DMA queue, guarded allocations.  See emu.h.
+#include "emu.h"
+
+#include <sys/mman.h>
+#include <ucontext.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <vector>
+
+namespace emu {
+
+dim3 g_block_idx, g_block_dim, g_grid_dim;
+
+namespace {
+
+enum State { READY, WAVEOP, BARRIER, DONE };
+
+struct Dma { void* dst; const void* src; int bytes; };
+
+struct Fiber {
+  ucontext_t ctx;
+  LaneInfo info;
+  State state = DONE;
+  Op op;
+  const void* tag;
+  const void* in;
+  void* out;
+  std::deque<Dma> dma;
+  unsigned char* stack = nullptr;
+};
+
+constexpr size_t STACK_BYTES = 512 * 1024;
+constexpr int MAX_THREADS = 1024;
+
+std::vector<Fiber> g_fibers;
+ucontext_t g_main;
+Fiber* g_cur = nullptr;
+const std::function<void()>* g_body = nullptr;
+unsigned char* g_smem_map = nullptr;
+size_t g_smem_map_bytes = 0;
+unsigned char* g_smem = nullptr;
+int g_dma_lazy = 1;
+long long g_launches = 0, g_waveops = 0;
+uint64_t g_clock = 0;
+
+[[noreturn]] void die(const char* what) {
+  fprintf(stderr, "emu: %s (block %u,%u thread %d)\n", what, g_block_idx.x, g_block_idx.y, g_cur ? g_cur->info.flat : -1);
+  fflush(stderr);
+  abort();
+}
+
+void yield_to_main() { swapcontext(&g_cur->ctx, &g_main); }
+
+void do_dma(const Dma& d) {
+  if (d.src) memcpy(d.dst, d.src, d.bytes);
+  else memset(d.dst, 0, d.bytes);
+}
+
+void trampoline() {
+  (*g_body)();
+  Fiber* f = g_cur;
+  while (!f->dma.empty()) { do_dma(f->dma.front()); f->dma.pop_front(); }
+  f->state = DONE;
+  yield_to_main();
+  die("resumed a finished fiber");
+}
+
+inline float bf16_bits_to_f32(uint16_t v) {
+  uint32_t u = (uint32_t)v << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+struct Mfma16In { uint16_t a[8], b[8]; float c[4]; };
+struct Mfma32In { uint16_t a[8], b[8]; float c[16]; };
+struct MfmaF32In { float a, b; float c[4]; };
+
+void need_full(int n, const char* what) {
+  if (n != 64) die(what);
+}
+
+// lanes[0..n) are the fibers parked at this operation, in lane order
+void run_op(Op op, Fiber** lanes, int n) {
+  g_waveops++;
+  switch (op) {
+    case OP_MFMA_16x16x32_BF16: {
+      need_full(n, "v_mfma_f32_16x16x32_bf16 with a partial EXEC mask");
+      static float A[16][32], B[32][16];
+      for (int l = 0; l < 64; ++l) {
+        const Mfma16In* in = static_cast<const Mfma16In*>(lanes[l]->in);
+        for (int j = 0; j < 8; ++j) {
+          A[l % 16][(l / 16) * 8 + j] = bf16_bits_to_f32(in->a[j]);
+          B[(l / 16) * 8 + j][l % 16] = bf16_bits_to_f32(in->b[j]);
+        }
+      }
+      for (int l = 0; l < 64; ++l) {
+        const Mfma16In* in = static_cast<const Mfma16In*>(lanes[l]->in);
+        float* out = static_cast<float*>(lanes[l]->out);
+        const int col = l % 16;
+        for (int r = 0; r < 4; ++r) {
+          const int row = (l / 16) * 4 + r;
+          double s = in->c[r];
+          for (int k = 0; k < 32; ++k) s += (double)A[row][k] * (double)B[k][col];
+          out[r] = (float)s;
+        }
+      }
+      break;
+    }
+    case OP_MFMA_32x32x16_BF16: {
+      need_full(n, "v_mfma_f32_32x32x16_bf16 with a partial EXEC mask");
+      static float A[32][16], B[16][32];
+      for (int l = 0; l < 64; ++l) {
+        const Mfma32In* in = static_cast<const Mfma32In*>(lanes[l]->in);
+        for (int j = 0; j < 8; ++j) {
+          A[l % 32][(l / 32) * 8 + j] = bf16_bits_to_f32(in->a[j]);
+          B[(l / 32) * 8 + j][l % 32] = bf16_bits_to_f32(in->b[j]);
+        }
+      }
+      for (int l = 0; l < 64; ++l) {
+        const Mfma32In* in = static_cast<const Mfma32In*>(lanes[l]->in);
+        float* out = static_cast<float*>(lanes[l]->out);
+        const int col = l % 32;
+        for (int r = 0; r < 16; ++r) {
+          const int row = 8 * (r / 4) + 4 * (l / 32) + (r % 4);
+          double s = in->c[r];
+          for (int k = 0; k < 16; ++k) s += (double)A[row][k] * (double)B[k][col];
+          out[r] = (float)s;
+        }
+      }
+      break;
+    }
+    case OP_MFMA_16x16x4_F32: {
+      need_full(n, "v_mfma_f32_16x16x4_f32 with a partial EXEC mask");
+      static float A[16][4], B[4][16];
+      for (int l = 0; l < 64; ++l) {
+        const MfmaF32In* in = static_cast<const MfmaF32In*>(lanes[l]->in);
+        A[l % 16][l / 16] = in->a;
+        B[l / 16][l % 16] = in->b;
+      }
+      for (int l = 0; l < 64; ++l) {
+        const MfmaF32In* in = static_cast<const MfmaF32In*>(lanes[l]->in);
+        float* out = static_cast<float*>(lanes[l]->out);
+        const int col = l % 16;
+        for (int r = 0; r < 4; ++r) {
+          const int row = (l / 16) * 4 + r;
+          float s = in->c[r];
+          for (int k = 0; k < 4; ++k) s = fmaf(A[row][k], B[k][col], s);
+          out[r] = s;
+        }
+      }
+      break;
+    }
+    case OP_SHFL: {
+      const Fiber* by_lane[64] = {};
+      for (int i = 0; i < n; ++i) by_lane[lanes[i]->info.lane] = lanes[i];
+      for (int i = 0; i < n; ++i) {
+        const ShflIn* in = static_cast<const ShflIn*>(lanes[i]->in);
+        const int l = lanes[i]->info.lane;
+        const int w = in->width;
+        const int base = l / w * w;
+        int s;
+        if (in->mode == 0) s = base + ((in->src % w) + w) % w;
+        else if (in->mode == 1) s = base + ((l - base) ^ in->src);
+        else if (in->mode == 2) s = (l - base) + in->src < w ? l + in->src : l;
+        else s = (l - base) - in->src >= 0 ? l - in->src : l;
+        if (s < 0 || s >= 64 || (in->mode == 1 && s >= base + w)) s = l;
+        if (!by_lane[s]) die("shuffle reads a lane that is not active at this call");
+        *static_cast<uint64_t*>(lanes[i]->out) = static_cast<const ShflIn*>(by_lane[s]->in)->value;
+      }
+      break;
+    }
+    case OP_READFIRSTLANE: {
+      const uint32_t v = *static_cast<const uint32_t*>(lanes[0]->in);
+      for (int i = 0; i < n; ++i) *static_cast<uint32_t*>(lanes[i]->out) = v;
+      break;
+    }
+    case OP_BALLOT: {
+      uint64_t m = 0;
+      for (int i = 0; i < n; ++i)
+        if (*static_cast<const int*>(lanes[i]->in)) m |= 1ull << lanes[i]->info.lane;
+      for (int i = 0; i < n; ++i) *static_cast<uint64_t*>(lanes[i]->out) = m;
+      break;
+    }
+    case OP_PERMLANE32_SWAP: {
+      // in: {vdst, src}; lanes 32..63 of vdst swap with lanes 0..31 of src
+      need_full(n, "v_permlane32_swap with a partial EXEC mask (emulator is strict)");
+      uint32_t vd[64], sr[64];
+      for (int l = 0; l < 64; ++l) {
+        const uint32_t* in = static_cast<const uint32_t*>(lanes[l]->in);
+        vd[l] = in[0];
+        sr[l] = in[1];
+      }
+      for (int l = 0; l < 64; ++l) {
+        uint32_t* out = static_cast<uint32_t*>(lanes[l]->out);
+        out[0] = l < 32 ? vd[l] : sr[l - 32];
+        out[1] = l < 32 ? vd[l + 32] : sr[l];
+      }
+      break;
+    }
+    case OP_PERMLANE16_SWAP: {
+      // rows of 16 lanes: odd rows of vdst swap with even rows of src (row 1 <-> row 0, row 3 <-> row 2)
+      need_full(n, "v_permlane16_swap with a partial EXEC mask (emulator is strict)");
+      uint32_t vd[64], sr[64];
+      for (int l = 0; l < 64; ++l) {
+        const uint32_t* in = static_cast<const uint32_t*>(lanes[l]->in);
+        vd[l] = in[0];
+        sr[l] = in[1];
+      }
+      for (int l = 0; l < 64; ++l) {
+        uint32_t* out = static_cast<uint32_t*>(lanes[l]->out);
+        const int row = l / 16;
+        out[0] = (row & 1) ? sr[l - 16] : vd[l];
+        out[1] = (row & 1) ? sr[l] : vd[l + 16];
+      }
+      break;
+    }
+    case OP_DS_READ_TR16_B64: {
+      // per 16-lane group: lane 4q+p supplies the address of row q, columns 4p..4p+3; lane i receives column i, row q in
+      // element q
+      need_full(n, "ds_read_b64_tr_b16 with a partial EXEC mask");
+      const unsigned char* addr[64];
+      for (int l = 0; l < 64; ++l) {
+        addr[l] = *static_cast<const unsigned char* const*>(lanes[l]->in);
+        if (reinterpret_cast<uintptr_t>(addr[l]) & 7) die("ds_read_b64_tr_b16: address not 8-byte aligned");
+      }
+      for (int l = 0; l < 64; ++l) {
+        uint16_t* out = static_cast<uint16_t*>(lanes[l]->out);
+        const int g = l / 16, i = l % 16;
+        for (int q = 0; q < 4; ++q) memcpy(&out[q], addr[16 * g + 4 * q + i / 4] + 2 * (i % 4), 2);
+      }
+      break;
+    }
+    case OP_WAVE_BARRIER:
+      break;
+    default:
+      die("unknown wave operation");
+  }
+}
+
+void run_block() {
+  const int nthreads = (int)(g_block_dim.x * g_block_dim.y * g_block_dim.z);
+  for (int t = 0; t < nthreads; ++t) {
+    Fiber& f = g_fibers[t];
+    f.info.flat = t;
+    f.info.lane = t % 64;
+    f.info.wave = t / 64;
+    f.info.tid = dim3(t % g_block_dim.x, (t / g_block_dim.x) % g_block_dim.y, t / (g_block_dim.x * g_block_dim.y));
+    f.state = READY;
+    f.dma.clear();
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = STACK_BYTES;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, trampoline, 0);
+  }
+  const int nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    bool ran = false;
+    for (int t = 0; t < nthreads; ++t) {
+      Fiber& f = g_fibers[t];
+      if (f.state != READY) continue;
+      g_cur = &f;
+      swapcontext(&g_main, &f.ctx);
+      g_cur = nullptr;
+      ran = true;
+    }
+    bool did = false;
+    for (int w = 0; w < nwaves; ++w) {
+      const int lo = w * 64, hi = std::min(nthreads, lo + 64);
+      // partition the parked lanes by (op, call site)
+      std::map<std::pair<int, const void*>, std::vector<Fiber*>> groups;
+      for (int t = lo; t < hi; ++t)
+        if (g_fibers[t].state == WAVEOP) groups[{(int)g_fibers[t].op, g_fibers[t].tag}].push_back(&g_fibers[t]);
+      for (auto& kv : groups) {
+        run_op((Op)kv.first.first, kv.second.data(), (int)kv.second.size());
+        for (Fiber* f : kv.second) f->state = READY;
+        did = true;
+      }
+    }
+    if (did) continue;
+    int at_barrier = 0, done = 0;
+    for (int t = 0; t < nthreads; ++t) {
+      at_barrier += g_fibers[t].state == BARRIER;
+      done += g_fibers[t].state == DONE;
+    }
+    if (done == nthreads) break;
+    if (at_barrier + done == nthreads && at_barrier > 0) {
+      for (int t = 0; t < nthreads; ++t)
+        if (g_fibers[t].state == BARRIER) g_fibers[t].state = READY;
+      continue;
+    }
+    if (!ran) die("deadlock: no lane can run");
+  }
+}
+
+void ensure_fibers(int n) {
+  if ((int)g_fibers.size() < n) {
+    const size_t old = g_fibers.size();
+    g_fibers.resize(n);
+    for (size_t i = old; i < g_fibers.size(); ++i) {
+      void* m = mmap(nullptr, STACK_BYTES + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+      if (m == MAP_FAILED) die("mmap of a fiber stack failed");
+      mprotect(m, 4096, PROT_NONE);    // stack overflow = fault, not silent corruption
+      g_fibers[i].stack = static_cast<unsigned char*>(m) + 4096;
+    }
+  }
+}
+
+}  // namespace
+
+const LaneInfo& me() { return g_cur->info; }
+unsigned char* dyn_smem() { return g_smem; }
+uint64_t clock_ticks() { return ++g_clock; }
+
+void wave_op(Op op, const void* tag, const void* in, void* out) {
+  Fiber* f = g_cur;
+  f->op = op;
+  f->tag = tag;
+  f->in = in;
+  f->out = out;
+  f->state = WAVEOP;
+  yield_to_main();
+}
+
+void barrier() {
+  g_cur->state = BARRIER;
+  yield_to_main();
+}
+
+void dma_to_lds(void* lds_dst, const void* src_or_null, int bytes) {
+  const Dma d{lds_dst, src_or_null, bytes};
+  if (g_dma_lazy) g_cur->dma.push_back(d);
+  else do_dma(d);
+}
+
+void wait_vmcnt(int n) {
+  Fiber* f = g_cur;
+  while ((int)f->dma.size() > n) {
+    do_dma(f->dma.front());
+    f->dma.pop_front();
+  }
+}
+
+void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body) {
+  const int nthreads = (int)(block.x * block.y * block.z);
+  if (nthreads < 1 || nthreads > MAX_THREADS) die("bad workgroup size");
+  if (dyn_smem_bytes > 160 * 1024) die("more than 160 KiB of dynamic LDS");
+  ensure_fibers(nthreads);
+  // dynamic LDS: ends on a guard page
+  const size_t need = (dyn_smem_bytes + 15) & ~size_t(15);
+  const size_t pages = (need + 4095) / 4096 * 4096;
+  if (g_smem_map_bytes < pages + 8192) {
+    if (g_smem_map) munmap(g_smem_map, g_smem_map_bytes);
+    g_smem_map_bytes = 160 * 1024 + 4096 + 8192;
+    g_smem_map = static_cast<unsigned char*>(mmap(nullptr, g_smem_map_bytes, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (g_smem_map == MAP_FAILED) die("mmap of the LDS image failed");
+  }
+  mprotect(g_smem_map, g_smem_map_bytes, PROT_NONE);
+  if (pages) mprotect(g_smem_map + 4096, pages, PROT_READ | PROT_WRITE);
+  g_smem = g_smem_map + 4096 + pages - need;
+  if (need) memset(g_smem, 0xA5, need);      // LDS starts out as garbage, not zeros
+  g_grid_dim = grid;
+  g_block_dim = block;
+  g_body = &body;
+  g_launches++;
+  for (unsigned z = 0; z < grid.z; ++z)
+    for (unsigned y = 0; y < grid.y; ++y)
+      for (unsigned x = 0; x < grid.x; ++x) {
+        g_block_idx = dim3(x, y, z);
+        run_block();
+      }
+  g_body = nullptr;
+}
+
+}  // namespace emu
+
+extern "C" {
+
+void emu_set_dma_mode(int lazy) { emu::g_dma_lazy = lazy ? 1 : 0; }
+
+struct GuardHeader { void* map; size_t map_bytes; };
+static std::map<void*, GuardHeader> g_guarded;
+
+void* emu_alloc_guarded(size_t bytes) {
+  const size_t need = (bytes + 15) & ~size_t(15);
+  const size_t pages = (need + 4095) / 4096 * 4096;
+  const size_t total = pages + 2 * 4096;
+  unsigned char* m = static_cast<unsigned char*>(mmap(nullptr, total, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (m == MAP_FAILED) return nullptr;
+  if (pages) mprotect(m + 4096, pages, PROT_READ | PROT_WRITE);
+  unsigned char* p = m + 4096 + pages - need;
+  g_guarded[p] = GuardHeader{m, total};
+  return p;
+}
+
+void emu_free_guarded(void* p) {
+  auto it = g_guarded.find(p);
+  if (it == g_guarded.end()) return;
+  munmap(it->second.map, it->second.map_bytes);
+  g_guarded.erase(it);
+}
+
+long long emu_launch_count() { return emu::g_launches; }
+long long emu_waveop_count() { return emu::g_waveops; }
+
+}

@@ -1,0 +1,142 @@
+"""Runs the product's Python front ends (ldm.ops, ldm.unet ...) on CPU tensors against libldm_emu.so, the kernel sources
+compiled for the host on the SIMT emulator (tests/emu/emu.h).  TEST INFRASTRUCTURE: the patches below exist only inside
+the ``emulated()`` context of a test; the product has no CPU path and refuses CPU tensors everywhere else."""
+import contextlib
+import ctypes as C
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import build_emu  # noqa: E402
+
+_emu = None
+
+
+def emu_lib():
+    """libldm_emu.so with the product's ctypes signatures (built on first use)."""
+    global _emu
+    if _emu is not None:
+        return _emu
+    from ldm import _lib
+    path = build_emu.build()
+    lib = C.CDLL(path)
+    lib.ldm_abi_version.restype = C.c_int
+    lib.ldm_abi_version.argtypes = []
+    lib.ldm_last_error.restype = C.c_char_p
+    lib.ldm_last_error.argtypes = []
+    for name, argtypes in _lib._SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    lib.ldm_conv_wgrad_workspace_bytes.restype = C.c_longlong
+    lib.ldm_conv_wgrad_workspace_bytes.argtypes = [C.POINTER(_lib.ConvGemmDesc)]
+    for name, argtypes in _lib._LONGLONG_QUERIES.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_longlong
+        fn.argtypes = argtypes
+    lib.emu_set_dma_mode.argtypes = [C.c_int]
+    lib.emu_set_dma_mode.restype = None
+    lib.emu_alloc_guarded.argtypes = [C.c_size_t]
+    lib.emu_alloc_guarded.restype = C.c_void_p
+    lib.emu_free_guarded.argtypes = [C.c_void_p]
+    lib.emu_free_guarded.restype = None
+    lib.emu_launch_count.restype = C.c_longlong
+    lib.emu_waveop_count.restype = C.c_longlong
+    assert lib.ldm_abi_version() == _lib.ABI_VERSION
+    _emu = lib
+    return lib
+
+
+class _NullStream:
+    cuda_stream = 0
+
+    def wait_stream(self, other):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+_leaky = None
+
+
+def _guarded_empty(*size, dtype=None, device=None, **kw):
+    """torch.empty on guarded pages (never freed: the tensors escape into the test)."""
+    global _leaky
+    if _leaky is None:
+        _leaky = Guarded()
+    if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+        size = tuple(size[0])
+    return _leaky.empty(tuple(int(v) for v in size), dtype or torch.get_default_dtype())
+
+
+@contextlib.contextmanager
+def emulated(dma="lazy", guard=False):
+    """Inside: ldm._lib.load() returns the emulator library and ldm.ops accepts CPU tensors.  dma: "lazy" (an LDS-DMA
+    lands when a counted wait retires it) or "eager" (when it is issued).  guard: every torch.empty (the outputs and
+    workspaces the front ends allocate) ends on a PROT_NONE page."""
+    from ldm import _lib, ops
+    lib = emu_lib()
+    lib.emu_set_dma_mode(1 if dma == "lazy" else 0)
+    saved = (_lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty)
+    saved_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize)
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the bodies of the GPU tests run unchanged on CPU tensors
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.Tensor.is_cuda = property(lambda self: True)      # shadows TensorBase.is_cuda for the product's device checks
+    if guard:
+        torch.empty = _guarded_empty
+    _lib._lib = lib
+    ops._gpu = lambda *ts: None
+    ops._stream = lambda t: 0
+    torch.cuda.device = lambda dev: contextlib.nullcontext()
+    torch.cuda.current_stream = lambda device=None: _NullStream()
+    try:
+        yield ops
+    finally:
+        _lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty = saved
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize = saved_cuda
+        del torch.Tensor.is_cuda
+        lib.emu_set_dma_mode(1)
+
+
+class Guarded:
+    """CPU tensors whose storage ends on a PROT_NONE page: one byte past the end is a SIGSEGV (and one page before the
+    start too).  Keep the object alive as long as the tensors are used."""
+
+    def __init__(self):
+        self._ptrs = []
+
+    def like(self, t: torch.Tensor) -> torch.Tensor:
+        t = t.contiguous()
+        nbytes = t.numel() * t.element_size()
+        lib = emu_lib()
+        p = lib.emu_alloc_guarded(max(nbytes, 1))
+        assert p
+        self._ptrs.append(p)
+        if nbytes == 0:
+            return t.clone()
+        buf = (C.c_char * nbytes).from_address(p)
+        g = torch.frombuffer(buf, dtype=torch.uint8, count=nbytes).view(t.dtype).view(t.shape)
+        g.copy_(t)
+        return g
+
+    def empty(self, shape, dtype) -> torch.Tensor:
+        return self.like(torch.zeros(shape, dtype=dtype))
+
+    def close(self):
+        lib = emu_lib()
+        for p in self._ptrs:
+            lib.emu_free_guarded(p)
+        self._ptrs = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
