@@ -18,13 +18,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+EMULATE = os.environ.get("LDM_EMU") == "1"      # run the bodies of the -m gpu tests on the host SIMT emulator (tests/emu)
+
+
 def pytest_collection_modifyitems(config, items):
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() or EMULATE:
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _emulated_gpu(request):
+    """LDM_EMU=1: every gpu-marked test runs inside tests/emu/harness.emulated(guard=True) -- the kernel sources compiled
+    for the host, CPU tensors on guard pages.  LDM_EMU_DMA=eager selects the other LDS-DMA completion model."""
+    if EMULATE and "gpu" in request.keywords:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        from harness import emulated
+        with emulated(os.environ.get("LDM_EMU_DMA", "lazy"), guard=True):
+            yield
+    else:
+        yield
 
 
 @pytest.fixture(scope="session")

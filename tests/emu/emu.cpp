@@ -1,6 +1,8 @@
 // Host-side SIMT emulator: scheduler, cross-lane operations, LDS-DMA queue, guarded allocations.  See emu.h.
 #include "emu.h"
 
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <ucontext.h>
 #include <unistd.h>
@@ -78,9 +80,9 @@ inline float bf16_bits_to_f32(uint16_t v) {
   return f;
 }
 
-struct Mfma16In { uint16_t a[8], b[8]; float c[4]; };
-struct Mfma32In { uint16_t a[8], b[8]; float c[16]; };
-struct MfmaF32In { float a, b; float c[4]; };
+struct Mfma16In { alignas(16) uint16_t a[8]; alignas(16) uint16_t b[8]; alignas(16) float c[4]; };
+struct Mfma32In { uint16_t a[8], b[8]; alignas(64) float c[16]; };   // as the shim's { bf16x8 a, b; f32x16 c; }
+struct MfmaF32In { float a, b; alignas(16) float c[4]; };   // as the shim's { float a, b; f32x4 c; }
 
 void need_full(int n, const char* what) {
   if (n != 64) die(what);
@@ -300,6 +302,42 @@ void run_block() {
   }
 }
 
+// SIGSEGV report: which lane of which workgroup touched what (a guard page behind LDS or behind a guarded buffer), with a
+// backtrace into the kernel source (-g1 line tables: addr2line -e libldm_emu.so <pc>)
+void on_segv(int sig, siginfo_t* si, void*) {
+  char buf[512];
+  const unsigned char* a = static_cast<const unsigned char*>(si->si_addr);
+  const char* where = "outside the emulator's regions";
+  long rel = 0;
+  if (g_smem_map && a >= g_smem_map && a < g_smem_map + g_smem_map_bytes) {
+    where = "LDS image (offset from the dynamic LDS base)";
+    rel = (long)(a - g_smem);
+  }
+  int n = snprintf(buf, sizeof buf, "emu: SIGSEGV at %p: %s %ld; block (%u,%u,%u) thread %d\n", (void*)a, where, rel,
+                   g_block_idx.x, g_block_idx.y, g_block_idx.z, g_cur ? g_cur->info.flat : -1);
+  if (write(2, buf, n)) {}
+  void* bt[32];
+  const int m = backtrace(bt, 32);
+  backtrace_symbols_fd(bt, m, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
+void install_segv_handler() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  static unsigned char alt[64 * 1024];
+  stack_t ss{};
+  ss.ss_sp = alt;
+  ss.ss_size = sizeof alt;
+  sigaltstack(&ss, nullptr);
+  struct sigaction sa{};
+  sa.sa_sigaction = on_segv;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK | SA_RESETHAND;
+  sigaction(SIGSEGV, &sa, nullptr);
+}
+
 void ensure_fibers(int n) {
   if ((int)g_fibers.size() < n) {
     const size_t old = g_fibers.size();
@@ -353,6 +391,7 @@ void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<vo
   if (nthreads < 1 || nthreads > MAX_THREADS) die("bad workgroup size");
   if (dyn_smem_bytes > 160 * 1024) die("more than 160 KiB of dynamic LDS");
   ensure_fibers(nthreads);
+  if (getenv("LDM_EMU_SEGV_REPORT")) install_segv_handler();
   // dynamic LDS: ends on a guard page
   const size_t need = (dyn_smem_bytes + 15) & ~size_t(15);
   const size_t pages = (need + 4095) / 4096 * 4096;

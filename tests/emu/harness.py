@@ -75,6 +75,25 @@ def _guarded_empty(*size, dtype=None, device=None, **kw):
     return _leaky.empty(tuple(int(v) for v in size), dtype or torch.get_default_dtype())
 
 
+_FACTORIES = ("randn", "rand", "zeros", "ones", "empty", "full", "tensor", "arange", "randint", "zeros_like", "ones_like",
+              "empty_like", "randn_like", "as_tensor", "linspace", "eye")
+
+
+def _cpu_device(fn):
+    """fn with device="cuda..." rewritten to the CPU (the GPU tests name the device in their factory calls)."""
+    def wrapped(*a, **k):
+        d = k.get("device")
+        if d is not None and str(d).startswith("cuda"):
+            k["device"] = "cpu"
+        return fn(*a, **k)
+    return wrapped
+
+
+class _CpuGenerator(torch.Generator):
+    def __new__(cls, device="cpu"):
+        return super().__new__(cls, "cpu")
+
+
 @contextlib.contextmanager
 def emulated(dma="lazy", guard=False):
     """Inside: ldm._lib.load() returns the emulator library and ldm.ops accepts CPU tensors.  dma: "lazy" (an LDS-DMA
@@ -91,6 +110,18 @@ def emulated(dma="lazy", guard=False):
     torch.Tensor.is_cuda = property(lambda self: True)      # shadows TensorBase.is_cuda for the product's device checks
     if guard:
         torch.empty = _guarded_empty
+    saved_fact = {n: getattr(torch, n) for n in _FACTORIES}
+    for n in _FACTORIES:
+        setattr(torch, n, _cpu_device(getattr(torch, n)))
+    saved_gen, saved_to = torch.Generator, torch.Tensor.to
+    torch.Generator = _CpuGenerator
+
+    def _to(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, (str, torch.device)) and str(x).startswith("cuda")) else x for x in a)
+        if "device" in k and k["device"] is not None and str(k["device"]).startswith("cuda"):
+            k["device"] = "cpu"
+        return saved_to(self, *a, **k)
+    torch.Tensor.to = _to
     _lib._lib = lib
     ops._gpu = lambda *ts: None
     ops._stream = lambda t: 0
@@ -102,6 +133,9 @@ def emulated(dma="lazy", guard=False):
         _lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty = saved
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize = saved_cuda
         del torch.Tensor.is_cuda
+        for n, f in saved_fact.items():
+            setattr(torch, n, f)
+        torch.Generator, torch.Tensor.to = saved_gen, saved_to
         lib.emu_set_dma_mode(1)
 
 

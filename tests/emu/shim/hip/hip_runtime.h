@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -90,6 +91,7 @@ template <typename A, typename B, typename C>
 EMU_NOINLINE C mfma_f32_16x16x32_bf16(A a, B b, C c, int, int, int) {
   static_assert(sizeof(A) == 16 && sizeof(B) == 16 && sizeof(C) == 16, "operand sizes");
   struct { A a; B b; C c; } in{a, b, c};
+  static_assert(offsetof(decltype(in), c) == 32 && offsetof(decltype(in), b) == 16, "layout the emulator reads");
   C out;
   wave_op(OP_MFMA_16x16x32_BF16, __builtin_return_address(0), &in, &out);
   return out;
@@ -98,6 +100,7 @@ template <typename A, typename B, typename C>
 EMU_NOINLINE C mfma_f32_32x32x16_bf16(A a, B b, C c, int, int, int) {
   static_assert(sizeof(A) == 16 && sizeof(B) == 16 && sizeof(C) == 64, "operand sizes");
   struct { A a; B b; C c; } in{a, b, c};
+  static_assert(offsetof(decltype(in), c) == 64 && offsetof(decltype(in), b) == 16, "layout the emulator reads");
   C out;
   wave_op(OP_MFMA_32x32x16_BF16, __builtin_return_address(0), &in, &out);
   return out;
@@ -106,6 +109,7 @@ template <typename C>
 EMU_NOINLINE C mfma_f32_16x16x4f32(float a, float b, C c, int, int, int) {
   static_assert(sizeof(C) == 16, "operand sizes");
   struct { float a, b; C c; } in{a, b, c};
+  static_assert(offsetof(decltype(in), c) == 16, "layout the emulator reads");
   C out;
   wave_op(OP_MFMA_16x16x4_F32, __builtin_return_address(0), &in, &out);
   return out;
@@ -169,18 +173,25 @@ static inline rsrc_t make_buffer_rsrc(void* p, int /*stride*/, int num, int /*fl
 }
 // Range check as LLVM documents the raw buffer intrinsics: voffset (+ immediate) is checked against the record count, the
 // scalar offset is EXCLUDED from the check -- an in-range voffset with a scalar offset that carries the access past the end
-// reads past the end (here: into the guard page of a guarded allocation).
+// reads past the end (here: into the guard page of a guarded allocation).  LDM_EMU_SOFF_CHECKED=1 switches to the other
+// reading (scalar offset included in the check), to tell which kernels depend on it.
+static inline bool soff_checked() {
+  static const bool v = getenv("LDM_EMU_SOFF_CHECKED") != nullptr && getenv("LDM_EMU_SOFF_CHECKED")[0] == '1';
+  return v;
+}
 static inline void raw_ptr_buffer_load_lds(rsrc_t rs, void* lds, int size, unsigned voff, int soff, int imm, int) {
   // LDS address = wave-uniform base + lane * size (the instruction writes lane-linear)
-  const unsigned long long chk = (unsigned long long)voff + (unsigned)imm;
+  const unsigned long long chk = (unsigned long long)voff + (unsigned)imm + (soff_checked() ? (unsigned)soff : 0u);
+  const unsigned long long off = (unsigned long long)voff + (unsigned)imm + (unsigned)soff;
   unsigned char* dst = static_cast<unsigned char*>(lds) + me().lane * size;
-  dma_to_lds(dst, chk + size <= rs.bytes ? rs.base + chk + (unsigned)soff : nullptr, size);
+  dma_to_lds(dst, chk + size <= rs.bytes ? rs.base + off : nullptr, size);
 }
 typedef unsigned u32x4_emu __attribute__((ext_vector_type(4)));
 static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int) {
-  const unsigned long long chk = (unsigned long long)(unsigned)voff;
+  const unsigned long long chk = (unsigned long long)(unsigned)voff + (soff_checked() ? (unsigned)soff : 0u);
+  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
   u32x4_emu r{0, 0, 0, 0};
-  if (chk + 16 <= rs.bytes) memcpy(&r, rs.base + chk + (unsigned)soff, 16);
+  if (chk + 16 <= rs.bytes) memcpy(&r, rs.base + off, 16);
   return r;
 }
 
