@@ -66,10 +66,15 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16_32(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, b2));
 }
 
+// The wave-uniform tile offset goes into the DESCRIPTOR (base advanced, record count shrunk), not into the instruction's
+// scalar-offset field: LLVM documents soffset as EXCLUDED from the range check of raw buffer loads, and the rows past lk
+// of the last, ragged tile must come back as zeros (never as whatever lies behind this (sample, head)'s rows).
 __device__ __forceinline__ uint4 buffer_load16_32(const void* base, unsigned bytes, unsigned voff, unsigned soff) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  const unsigned left = bytes - soff;   // callers fetch existing tiles only: soff < bytes (a clamped form compiles to a VALU saturating subtract and drags the descriptor into a waterfall loop)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(static_cast<const unsigned char*>(base) + soff), 0, (int)left, 0x00020000);
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 

@@ -46,10 +46,15 @@ struct AbGeom {
   static constexpr int NBUF = D <= 80 ? 2 : 1;       // double-buffered tiles when they fit comfortably
 };
 
+// The wave-uniform tile offset goes into the DESCRIPTOR (base advanced, record count shrunk), not into the instruction's
+// scalar-offset field: LLVM documents soffset as EXCLUDED from the range check of raw buffer loads, and the rows past lk
+// of the last, ragged tile must come back as zeros (never as whatever lies behind this (sample, head)'s rows).
 __device__ __forceinline__ uint4 ab_buffer_load16(const void* base, unsigned bytes, unsigned voff, unsigned soff) {
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+  const unsigned left = bytes - soff;   // callers fetch existing tiles only: soff < bytes (a clamped form compiles to a VALU saturating subtract and drags the descriptor into a waterfall loop)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char*>(static_cast<const unsigned char*>(base) + soff), 0, (int)left, 0x00020000);
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0);
   return make_uint4(r[0], r[1], r[2], r[3]);
 }
 
