@@ -325,6 +325,26 @@ def main():
                 "roofline": roof}
             if world == 1 and not args.no_cpu_baseline and LAT == 64 and not args.strong:
                 out["cpu_baseline"] = cpu_baseline()
+        # A/B inside the same process and on the same device (devices of the pool differ by up to 10 %): the same steps once more
+        # with the LayerNorm fold switched off (separate LayerNorm kernels).  Outside the timed region of `value`; one rank only.
+        if world == 1 and not args.strong and out is not None and out["config"].get("layernorm_fold_active") \
+                and os.environ.get("LDM_BENCH_AB", "1") != "0":
+            from ldm import unet as _unet
+            _unet._LN_FOLD = False
+            net.invalidate_packed_weights()
+            try:
+                with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    for i in range(args.warmup):
+                        lat = one_step(i)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        lat = one_step(i)
+                    barrier()
+                    out["config"]["ms_per_step_without_layernorm_fold"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 3)
+            finally:
+                _unet._LN_FOLD = True
+                net.invalidate_packed_weights()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
