@@ -131,6 +131,45 @@ def roofline_from_log(log, elapsed, workload_key):
     return roof, gemm_time / elapsed
 
 
+def hbm_kernel_rows(dev, sched, ops):
+    """Achieved HBM rate of the memory-bound kernels of the path at sizes where a rate means something (the step itself runs
+    them at launch-bound sizes): scheduler step and add_noise on (256, 4, 64, 64) float32 latents -- BASELINE.json configs[2]'s
+    whole job in one launch -- GroupNorm + SiLU and LayerNorm on the 64x64 level's activation (32 x 4096 x 320, bf16).  HIP events
+    on torch's current stream, the stream these kernels are launched on; algorithmic bytes = every operand read once + every
+    result written once.  Outside every timed region."""
+    def timeit(fn, iters=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e3 / iters       # microseconds per launch
+
+    rows = []
+    g = torch.Generator(device=dev).manual_seed(7)
+    shape = (256, 4, 64, 64)
+    eps, x, noise = (torch.randn(shape, device=dev, generator=g) for _ in range(3))
+    n = eps.numel()
+    t_mid = sched.timesteps[len(sched.timesteps) // 2]
+    us = timeit(lambda: sched.step(eps, t_mid, x, noise=noise))
+    rows.append(("ddpm_step_kernel (eps, x_t, noise -> prev, x0)", list(shape), 5 * 4 * n, us))
+    tt = torch.randint(0, 1000, (shape[0],), device=dev, generator=g)
+    us = timeit(lambda: sched.add_noise(x, noise, tt))
+    rows.append(("ddpm_add_noise_kernel (x0, noise -> noisy)", list(shape), 3 * 4 * n, us))
+    a = torch.randn(32, 64, 64, 320, device=dev, generator=g).bfloat16()
+    gam, bet = torch.ones(320, device=dev), torch.zeros(320, device=dev)
+    us = timeit(lambda: ops.groupnorm(a, gam, bet, 32, silu=True))
+    rows.append(("gn_fused_kernel (GroupNorm + SiLU, one read + one write)", list(a.shape), 2 * 2 * a.numel(), us))
+    a3 = a.view(32, 4096, 320)
+    us = timeit(lambda: ops.layernorm(a3, gam, bet))
+    rows.append(("layernorm_kernel", list(a3.shape), 2 * 2 * a3.numel(), us))
+    return [{"kernel": k, "shape": sh, "algorithmic_bytes": b, "us_per_launch": round(u, 2), "GB_per_s": round(b / u / 1e3, 1),
+             "frac_of_hbm_peak": round(b / u / 1e3 / 8000.0, 3)} for k, sh, b, u in rows]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -325,6 +364,13 @@ def main():
                 "roofline": roof}
             if world == 1 and not args.no_cpu_baseline and LAT == 64 and not args.strong:
                 out["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.strong and not args.train and out is not None and LAT == 64 \
+                and os.environ.get("LDM_BENCH_AB", "1") != "0":
+            try:
+                with torch.no_grad():
+                    out["config"]["hbm_kernels"] = hbm_kernel_rows(dev, sched, ops)
+            except Exception as exc:   # a side measurement never costs the headline line
+                out["config"]["hbm_kernels"] = f"failed: {type(exc).__name__}: {exc}"
         # A/B inside the same process and on the same device (devices of the pool differ by up to 10 %): the same steps once more
         # with the LayerNorm fold switched off (separate LayerNorm kernels).  Outside the timed region of `value`; one rank only.
         if world == 1 and not args.strong and out is not None and out["config"].get("layernorm_fold_active") \
@@ -342,6 +388,8 @@ def main():
                         lat = one_step(i)
                     barrier()
                     out["config"]["ms_per_step_without_layernorm_fold"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 3)
+            except Exception as exc:
+                out["config"]["ms_per_step_without_layernorm_fold"] = f"failed: {type(exc).__name__}: {exc}"
             finally:
                 _unet._LN_FOLD = True
                 net.invalidate_packed_weights()

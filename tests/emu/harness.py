@@ -104,6 +104,8 @@ def emulated(dma="lazy", guard=False):
     lib.emu_set_dma_mode(1 if dma == "lazy" else 0)
     saved = (_lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty)
     saved_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize)
+    saved_cap = torch.cuda.is_current_stream_capturing
+    torch.cuda.is_current_stream_capturing = lambda: False
     torch.Tensor.cuda = lambda self, *a, **k: self          # the bodies of the GPU tests run unchanged on CPU tensors
     torch.nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.synchronize = lambda *a, **k: None
@@ -132,6 +134,7 @@ def emulated(dma="lazy", guard=False):
     finally:
         _lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty = saved
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize = saved_cuda
+        torch.cuda.is_current_stream_capturing = saved_cap
         del torch.Tensor.is_cuda
         for n, f in saved_fact.items():
             setattr(torch, n, f)
