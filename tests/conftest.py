@@ -30,17 +30,13 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(autouse=True)
-def _emulated_gpu(request):
-    """LDM_EMU=1: every gpu-marked test runs inside tests/emu/harness.emulated(guard=True) -- the kernel sources compiled
-    for the host, CPU tensors on guard pages.  LDM_EMU_DMA=eager selects the other LDS-DMA completion model."""
-    if EMULATE and "gpu" in request.keywords:
-        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
-        from harness import emulated
-        with emulated(os.environ.get("LDM_EMU_DMA", "lazy"), guard=True):
-            yield
-    else:
-        yield
+if EMULATE:
+    # LDM_EMU=1: the whole session (module-scoped fixtures included) runs inside tests/emu/harness.emulated(guard=True) -- the
+    # kernel sources compiled for the host, CPU tensors on guard pages.  LDM_EMU_DMA=eager selects the other LDS-DMA model.
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from harness import emulated as _emulated
+    _emu_session = _emulated(os.environ.get("LDM_EMU_DMA", "lazy"), guard=True)
+    _emu_session.__enter__()
 
 
 @pytest.fixture(scope="session")

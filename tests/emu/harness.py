@@ -105,6 +105,8 @@ def emulated(dma="lazy", guard=False):
     saved = (_lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty)
     saved_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize)
     saved_cap = torch.cuda.is_current_stream_capturing
+    saved_pin = torch.Tensor.pin_memory
+    torch.Tensor.pin_memory = lambda self, *a, **k: self
     torch.cuda.is_current_stream_capturing = lambda: False
     torch.Tensor.cuda = lambda self, *a, **k: self          # the bodies of the GPU tests run unchanged on CPU tensors
     torch.nn.Module.cuda = lambda self, *a, **k: self
@@ -135,6 +137,7 @@ def emulated(dma="lazy", guard=False):
         _lib._lib, ops._gpu, ops._stream, torch.cuda.device, torch.cuda.current_stream, torch.empty = saved
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize = saved_cuda
         torch.cuda.is_current_stream_capturing = saved_cap
+        torch.Tensor.pin_memory = saved_pin
         del torch.Tensor.is_cuda
         for n, f in saved_fact.items():
             setattr(torch, n, f)

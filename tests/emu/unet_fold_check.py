@@ -68,7 +68,10 @@ def main():
             out[fold] = y.float().clone()
     d = rel_l2(out[True], out[False])
     print(f"fold vs no fold: {d:.3e}")
-    ok = d < 2e-2 and rel_l2(out[True], ref) < max(2e-2, 1.5 * rel_l2(out[False], ref))
+    # two bf16 evaluations with independent rounding differ from each other by about the root sum of squares of their own
+    # errors; the folded form must not be worse than the unfused one by more than a quarter
+    e_fold, e_plain = rel_l2(out[True], ref), rel_l2(out[False], ref)
+    ok = e_fold < max(2e-2, 1.25 * e_plain) and d < 1.5 * (e_fold ** 2 + e_plain ** 2) ** 0.5
     print("OK" if ok else "MISMATCH")
     return 0 if ok else 1
 
