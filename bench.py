@@ -131,14 +131,14 @@ def roofline_from_log(log, elapsed, workload_key):
     return roof, gemm_time / elapsed
 
 
-def hbm_kernel_rows(dev, sched, ops):
+def hbm_kernel_rows(dev, sched, ops, iters=20, warm=3):
     """Achieved HBM rate of the memory-bound kernels of the path at sizes where a rate means something (the step itself runs
     them at launch-bound sizes): scheduler step and add_noise on (256, 4, 64, 64) float32 latents -- BASELINE.json configs[2]'s
     whole job in one launch -- GroupNorm + SiLU and LayerNorm on the 64x64 level's activation (32 x 4096 x 320, bf16).  HIP events
     on torch's current stream, the stream these kernels are launched on; algorithmic bytes = every operand read once + every
     result written once.  Outside every timed region."""
-    def timeit(fn, iters=20):
-        for _ in range(3):
+    def timeit(fn):
+        for _ in range(warm):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
