@@ -72,7 +72,10 @@ def _guarded_empty(*size, dtype=None, device=None, **kw):
         _leaky = Guarded()
     if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
         size = tuple(size[0])
-    return _leaky.empty(tuple(int(v) for v in size), dtype or torch.get_default_dtype())
+    t = _leaky.empty(tuple(int(v) for v in size), dtype or torch.get_default_dtype())
+    if t.numel():      # 0xFF bytes: NaN in float32 / bfloat16, -1 in integers -- an element a kernel forgets to write shows up
+        t.view(torch.uint8).fill_(0xFF)
+    return t
 
 
 _FACTORIES = ("randn", "rand", "zeros", "ones", "empty", "full", "tensor", "arange", "randint", "zeros_like", "ones_like",
