@@ -161,7 +161,7 @@ def build(force=False, verbose=False):
                                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
     eobj = os.path.join(OUT_DIR, "emu.o")
-    procs.append(("emu.cpp", subprocess.Popen([CLANG, "-std=c++20", "-O2", "-g1", "-fPIC", "-I", HERE, "-c", os.path.join(HERE, "emu.cpp"),
+    procs.append(("emu.cpp", subprocess.Popen([CLANG, "-std=c++20", "-O2", "-g1", "-fPIC", "-march=native", "-I", HERE, "-c", os.path.join(HERE, "emu.cpp"),
                                                "-o", eobj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs.append(eobj)
     failed = False

@@ -4,7 +4,6 @@
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/mman.h>
-#include <ucontext.h>
 #include <unistd.h>
 
 #include <cmath>
@@ -25,8 +24,40 @@ enum State { READY, WAVEOP, BARRIER, DONE };
 
 struct Dma { void* dst; const void* src; int bytes; };
 
+// Context switch: callee-saved registers on the fiber's own stack, the stack pointer in the Fiber (ucontext's swapcontext
+// costs two sigprocmask system calls per switch; a wave operation switches 128 times).
+extern "C" void emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  subq $8, %rsp
+  stmxcsr (%rsp)
+  fnstcw 4(%rsp)
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  ldmxcsr (%rsp)
+  fldcw 4(%rsp)
+  addq $8, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_switch,.-emu_switch
+)");
+
 struct Fiber {
-  ucontext_t ctx;
+  void* sp = nullptr;
   LaneInfo info;
   State state = DONE;
   Op op;
@@ -41,7 +72,7 @@ constexpr size_t STACK_BYTES = 512 * 1024;
 constexpr int MAX_THREADS = 1024;
 
 std::vector<Fiber> g_fibers;
-ucontext_t g_main;
+void* g_main_sp = nullptr;
 Fiber* g_cur = nullptr;
 const std::function<void()>* g_body = nullptr;
 unsigned char* g_smem_map = nullptr;
@@ -57,7 +88,7 @@ uint64_t g_clock = 0;
   abort();
 }
 
-void yield_to_main() { swapcontext(&g_cur->ctx, &g_main); }
+void yield_to_main() { emu_switch(&g_cur->sp, g_main_sp); }
 
 void do_dma(const Dma& d) {
   if (d.src) memcpy(d.dst, d.src, d.bytes);
@@ -80,6 +111,15 @@ inline float bf16_bits_to_f32(uint16_t v) {
   return f;
 }
 
+// sum_k a[k] * b[k] over n (a multiple of 8) floats: eight partial sums (the compiler turns them into one vector FMA per
+// step), folded pairwise, then the accumulator is added -- float32 throughout, like the matrix core's accumulation
+inline float dot_f32(const float* a, const float* b, int n, float c) {
+  float p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < n; k += 8)
+    for (int j = 0; j < 8; ++j) p[j] += a[k + j] * b[k + j];
+  return c + (((p[0] + p[4]) + (p[2] + p[6])) + ((p[1] + p[5]) + (p[3] + p[7])));
+}
+
 struct Mfma16In { alignas(16) uint16_t a[8]; alignas(16) uint16_t b[8]; alignas(16) float c[4]; };
 struct Mfma32In { uint16_t a[8], b[8]; alignas(64) float c[16]; };   // as the shim's { bf16x8 a, b; f32x16 c; }
 struct MfmaF32In { float a, b; alignas(16) float c[4]; };   // as the shim's { float a, b; f32x4 c; }
@@ -94,47 +134,37 @@ void run_op(Op op, Fiber** lanes, int n) {
   switch (op) {
     case OP_MFMA_16x16x32_BF16: {
       need_full(n, "v_mfma_f32_16x16x32_bf16 with a partial EXEC mask");
-      static float A[16][32], B[32][16];
+      alignas(32) static float A[16][32], Bt[16][32];
       for (int l = 0; l < 64; ++l) {
         const Mfma16In* in = static_cast<const Mfma16In*>(lanes[l]->in);
         for (int j = 0; j < 8; ++j) {
           A[l % 16][(l / 16) * 8 + j] = bf16_bits_to_f32(in->a[j]);
-          B[(l / 16) * 8 + j][l % 16] = bf16_bits_to_f32(in->b[j]);
+          Bt[l % 16][(l / 16) * 8 + j] = bf16_bits_to_f32(in->b[j]);
         }
       }
       for (int l = 0; l < 64; ++l) {
         const Mfma16In* in = static_cast<const Mfma16In*>(lanes[l]->in);
         float* out = static_cast<float*>(lanes[l]->out);
         const int col = l % 16;
-        for (int r = 0; r < 4; ++r) {
-          const int row = (l / 16) * 4 + r;
-          double s = in->c[r];
-          for (int k = 0; k < 32; ++k) s += (double)A[row][k] * (double)B[k][col];
-          out[r] = (float)s;
-        }
+        for (int r = 0; r < 4; ++r) out[r] = dot_f32(A[(l / 16) * 4 + r], Bt[col], 32, in->c[r]);
       }
       break;
     }
     case OP_MFMA_32x32x16_BF16: {
       need_full(n, "v_mfma_f32_32x32x16_bf16 with a partial EXEC mask");
-      static float A[32][16], B[16][32];
+      alignas(32) static float A[32][16], Bt[32][16];
       for (int l = 0; l < 64; ++l) {
         const Mfma32In* in = static_cast<const Mfma32In*>(lanes[l]->in);
         for (int j = 0; j < 8; ++j) {
           A[l % 32][(l / 32) * 8 + j] = bf16_bits_to_f32(in->a[j]);
-          B[(l / 32) * 8 + j][l % 32] = bf16_bits_to_f32(in->b[j]);
+          Bt[l % 32][(l / 32) * 8 + j] = bf16_bits_to_f32(in->b[j]);
         }
       }
       for (int l = 0; l < 64; ++l) {
         const Mfma32In* in = static_cast<const Mfma32In*>(lanes[l]->in);
         float* out = static_cast<float*>(lanes[l]->out);
         const int col = l % 32;
-        for (int r = 0; r < 16; ++r) {
-          const int row = 8 * (r / 4) + 4 * (l / 32) + (r % 4);
-          double s = in->c[r];
-          for (int k = 0; k < 16; ++k) s += (double)A[row][k] * (double)B[k][col];
-          out[r] = (float)s;
-        }
+        for (int r = 0; r < 16; ++r) out[r] = dot_f32(A[8 * (r / 4) + 4 * (l / 32) + (r % 4)], Bt[col], 16, in->c[r]);
       }
       break;
     }
@@ -256,11 +286,19 @@ void run_block() {
     f.info.tid = dim3(t % g_block_dim.x, (t / g_block_dim.x) % g_block_dim.y, t / (g_block_dim.x * g_block_dim.y));
     f.state = READY;
     f.dma.clear();
-    getcontext(&f.ctx);
-    f.ctx.uc_stack.ss_sp = f.stack;
-    f.ctx.uc_stack.ss_size = STACK_BYTES;
-    f.ctx.uc_link = nullptr;
-    makecontext(&f.ctx, trampoline, 0);
+    // initial frame for emu_switch: [mxcsr|fpcw] r15 r14 r13 r12 rbx rbp <return address = trampoline>, 16-byte aligned so
+    // that the stack pointer is 8 modulo 16 on entry to trampoline, as after a call
+    {
+      uintptr_t top = reinterpret_cast<uintptr_t>(f.stack + STACK_BYTES) & ~uintptr_t(15);
+      uint64_t* spp = reinterpret_cast<uint64_t*>(top);
+      *--spp = 0;                                             // fake return address of trampoline (never returns)
+      *--spp = reinterpret_cast<uint64_t>(&trampoline);       // ret target of the first switch
+      for (int k = 0; k < 6; ++k) *--spp = 0;                 // rbp rbx r12 r13 r14 r15
+      uint32_t csr[2] = {0x1F80u, 0x037Fu};                   // default MXCSR, default x87 control word
+      --spp;
+      memcpy(spp, csr, 8);
+      f.sp = spp;
+    }
   }
   const int nwaves = (nthreads + 63) / 64;
   for (;;) {
@@ -269,7 +307,7 @@ void run_block() {
       Fiber& f = g_fibers[t];
       if (f.state != READY) continue;
       g_cur = &f;
-      swapcontext(&g_main, &f.ctx);
+      emu_switch(&g_main_sp, f.sp);
       g_cur = nullptr;
       ran = true;
     }
@@ -277,6 +315,19 @@ void run_block() {
     for (int w = 0; w < nwaves; ++w) {
       const int lo = w * 64, hi = std::min(nthreads, lo + 64);
       // partition the parked lanes by (op, call site)
+      {   // the common case: the whole wave parked at one operation
+        bool same = hi - lo == 64 && g_fibers[lo].state == WAVEOP;
+        for (int t = lo + 1; same && t < hi; ++t)
+          same = g_fibers[t].state == WAVEOP && g_fibers[t].op == g_fibers[lo].op && g_fibers[t].tag == g_fibers[lo].tag;
+        if (same) {
+          Fiber* all[64];
+          for (int t = lo; t < hi; ++t) all[t - lo] = &g_fibers[t];
+          run_op(g_fibers[lo].op, all, 64);
+          for (int t = lo; t < hi; ++t) g_fibers[t].state = READY;
+          did = true;
+          continue;
+        }
+      }
       std::map<std::pair<int, const void*>, std::vector<Fiber*>> groups;
       for (int t = lo; t < hi; ++t)
         if (g_fibers[t].state == WAVEOP) groups[{(int)g_fibers[t].op, g_fibers[t].tag}].push_back(&g_fibers[t]);

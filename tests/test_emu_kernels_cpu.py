@@ -215,3 +215,35 @@ def test_transformer_model_with_and_without_the_fold(golden):
         U._LN_FOLD = saved[1]
     assert rel_l2(y_fold, g["tmodel.out"]) < 2e-2 and rel_l2(y_plain, g["tmodel.out"]) < 2e-2
     assert rel_l2(y_fold, y_plain) < 1.5e-2
+
+
+def test_smoke_on_the_emulator():
+    """__graft_entry__.smoke() with the emulator in place of cuda:0: one denoise step of the small UNet, float32 and bf16, and
+    the fused scheduler step, against the oracle -- the whole product path (Python schedule, packing, every forward kernel
+    the small net uses) end to end on the host, buffers on guard pages."""
+    from ldm.scheduling_ddpm import DDPMScheduler
+    from ldm.unet import UNet
+    from oracle import scheduler_ref as sref
+    from oracle import unet_ref as uref
+    kw = dict(block_out_channels=[32, 64, 64, 64])
+    cfg = uref.UNetConfig(**kw)
+    sd = uref.fill_state_dict(uref.param_shapes(cfg), seed=7, **uref.WELL_CONDITIONED)
+    net = UNet(**kw)
+    net.load_state_dict(sd)
+    net.eval()
+    x, ctx, noise = seeded((2, 4, 8, 8), 11), seeded((2, 77, 768), 12), seeded((2, 4, 8, 8), 13)
+    t = 500
+    with torch.no_grad():
+        ref64 = uref.unet_forward({k: v.double() for k, v in sd.items()}, cfg, x.double(), t, ctx.double())
+        tb = uref.unet_forward({k: v.bfloat16() for k, v in sd.items()}, cfg, x.bfloat16(), t, ctx.bfloat16()).double()
+        with emulated("lazy", guard=True):
+            sch = DDPMScheduler(device=torch.device("cpu"))
+            sch.set_timesteps(50)
+            eps = net(x, t, ctx).clone()
+            epsb = net(x.bfloat16(), t, ctx.bfloat16()).clone()
+            prev = sch.step(eps, 500, x, noise=noise).prev_sample.clone()
+    assert rel_l2(eps, ref64) < 1e-4
+    bound = max(2e-2, 1.25 * rel_l2(tb, ref64))
+    assert rel_l2(epsb, ref64) < bound, (rel_l2(epsb, ref64), bound)
+    ref_prev, _ = sref.step(sref.build_tables(), eps, 500, 480, x, noise)
+    assert torch.equal(prev, ref_prev), "scheduler step is not bit-exact on the emulator"
