@@ -109,6 +109,10 @@ def emulated(dma="lazy", guard=False):
     saved_cuda = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize)
     saved_cap = torch.cuda.is_current_stream_capturing
     saved_pin = torch.Tensor.pin_memory
+    saved_mem = (torch.cuda.memory_allocated, torch.cuda.memory_reserved, torch.cuda.mem_get_info)
+    torch.cuda.memory_allocated = lambda *a, **k: 0
+    torch.cuda.memory_reserved = lambda *a, **k: 0
+    torch.cuda.mem_get_info = lambda *a, **k: (1 << 38, 1 << 38)
     torch.Tensor.pin_memory = lambda self, *a, **k: self
     torch.cuda.is_current_stream_capturing = lambda: False
     torch.Tensor.cuda = lambda self, *a, **k: self          # the bodies of the GPU tests run unchanged on CPU tensors
@@ -141,6 +145,7 @@ def emulated(dma="lazy", guard=False):
         torch.Tensor.cuda, torch.nn.Module.cuda, torch.cuda.synchronize = saved_cuda
         torch.cuda.is_current_stream_capturing = saved_cap
         torch.Tensor.pin_memory = saved_pin
+        torch.cuda.memory_allocated, torch.cuda.memory_reserved, torch.cuda.mem_get_info = saved_mem
         del torch.Tensor.is_cuda
         for n, f in saved_fact.items():
             setattr(torch, n, f)
