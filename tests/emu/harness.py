@@ -97,6 +97,37 @@ class _CpuGenerator(torch.Generator):
         return super().__new__(cls, "cpu")
 
 
+_real_autocast = torch.autocast
+
+
+class _Autocast:
+    """torch.autocast for the emulated session: a "cuda" region sets the CUDA autocast state the product looks at
+    (unet.compute_dtype_of) -- torch itself refuses to on a host without the device -- and opens a CPU autocast region of the
+    same dtype, so that torch's own ops on the CPU tensors cast the way they would on the device."""
+
+    def __init__(self, device_type, dtype=None, enabled=True, cache_enabled=None):
+        self.cuda = str(device_type).startswith("cuda")
+        self.dtype, self.enabled = dtype, enabled
+        self.inner = _real_autocast("cpu", dtype=dtype if dtype is not None else torch.bfloat16, enabled=enabled) if self.cuda \
+            else _real_autocast(device_type, dtype=dtype, enabled=enabled, cache_enabled=cache_enabled)
+
+    def __enter__(self):
+        if self.cuda:
+            self.prev = (torch.is_autocast_enabled("cuda"), torch.get_autocast_dtype("cuda"))
+            torch.set_autocast_enabled("cuda", bool(self.enabled))
+            if self.dtype is not None:
+                torch.set_autocast_dtype("cuda", self.dtype)
+        self.inner.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.inner.__exit__(*exc)
+        if self.cuda:
+            torch.set_autocast_enabled("cuda", self.prev[0])
+            torch.set_autocast_dtype("cuda", self.prev[1])
+        return False
+
+
 @contextlib.contextmanager
 def emulated(dma="lazy", guard=False):
     """Inside: ldm._lib.load() returns the emulator library and ldm.ops accepts CPU tensors.  dma: "lazy" (an LDS-DMA
@@ -126,6 +157,7 @@ def emulated(dma="lazy", guard=False):
         setattr(torch, n, _cpu_device(getattr(torch, n)))
     saved_gen, saved_to = torch.Generator, torch.Tensor.to
     torch.Generator = _CpuGenerator
+    torch.autocast = _Autocast
 
     def _to(self, *a, **k):
         a = tuple("cpu" if (isinstance(x, (str, torch.device)) and str(x).startswith("cuda")) else x for x in a)
@@ -150,6 +182,7 @@ def emulated(dma="lazy", guard=False):
         for n, f in saved_fact.items():
             setattr(torch, n, f)
         torch.Generator, torch.Tensor.to = saved_gen, saved_to
+        torch.autocast = _real_autocast
         lib.emu_set_dma_mode(1)
 
 

@@ -205,6 +205,16 @@ def test_transformer_model_with_and_without_the_fold(golden):
             U._LN_FOLD = True
             y_fold = net(x.to(bf), ctx.to(bf)).clone()
             assert net._packed_for(bf).get("ln_fold") is True
+            # the entry that faulted the GPU in round 2: float32 module and inputs inside a bf16 autocast region -- the filters
+            # are packed INSIDE the region, where torch's own ops return bf16
+            net.invalidate_packed_weights()
+            with torch.autocast("cuda", dtype=bf):
+                assert (torch.ones(2, 2) @ torch.ones(2, 2)).dtype == bf        # the region is live for torch's ops too
+                y_auto = net(x, ctx).clone()
+            P = net._packed_for(bf)
+            assert P.get("ln_fold") is True and all(v.dtype == torch.float32 for k, v in P.items()
+                                                    if k.endswith(".b_ln") or k.endswith(".s1"))
+            assert y_auto.dtype == bf and torch.equal(y_auto, y_fold)
             net.invalidate_packed_weights()
             U._LN_FOLD = False
             y_plain = net(x.to(bf), ctx.to(bf)).clone()
