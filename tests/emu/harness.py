@@ -74,7 +74,7 @@ def _guarded_empty(*size, dtype=None, device=None, **kw):
         size = tuple(size[0])
     t = _leaky.empty(tuple(int(v) for v in size), dtype or torch.get_default_dtype())
     if t.numel():      # 0xFF bytes: NaN in float32 / bfloat16, -1 in integers -- an element a kernel forgets to write shows up
-        t.view(torch.uint8).fill_(0xFF)
+        t.reshape(-1).view(torch.uint8).fill_(0xFF)
     return t
 
 
