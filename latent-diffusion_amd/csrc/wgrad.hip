@@ -251,8 +251,6 @@ conv_wgrad_bf16_v2_kernel(const WgradParams p) {
   const int nsteps = min(step_begin + p.steps_per_split, total_steps) - step_begin;
 
   const unsigned bytes_a0 = (unsigned)p.batch * p.hin * p.win * p.c0 * 2u;
-  const unsigned bytes_a1 = (unsigned)p.batch * p.hin * p.win * (p.c1 ? p.c1 : p.c0) * 2u;
-  const unsigned bytes_dy = (unsigned)p.M * p.N * 2u;
   const int hlim = p.upsample ? p.hin * 2 : p.hin, wlim = p.upsample ? p.win * 2 : p.win;
   const int pad = p.ksize >> 1;
   const float inv_w = 1.0f / (float)p.wout, inv_h = 1.0f / (float)p.hout;
