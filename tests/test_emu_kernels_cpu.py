@@ -257,3 +257,20 @@ def test_smoke_on_the_emulator():
     assert rel_l2(epsb, ref64) < bound, (rel_l2(epsb, ref64), bound)
     ref_prev, _ = sref.step(sref.build_tables(), eps, 500, 480, x, noise)
     assert torch.equal(prev, ref_prev), "scheduler step is not bit-exact on the emulator"
+
+
+def test_backward_and_small_kernels_through_the_gpu_tests_bodies():
+    """The bodies of 71 `-m gpu` operator tests, unchanged, on the emulator (LDM_EMU=1, tests/conftest.py): weight gradient
+    (3x3, strided, two sources, linear), input gradient, column sums, the GLU training form, GroupNorm / LayerNorm backward,
+    attention backward with a ragged 77-key tile, GroupNorm over a concat whose group straddles the sources, the timestep
+    embedding, conv_in / final conv, split-K.  In a child process: the session-wide patches of that mode stay out of this one."""
+    sel = ("conv_wgrad or linear_wgrad or conv_dgrad or colsum or glu_training or groupnorm_backward or layernorm_backward or "
+           "(attention_backward and 77) or concat_straddle or timestep_embedding or conv_in_out or split_k")
+    env = dict(os.environ, LDM_EMU="1")
+    env.pop("LDM_GEMM_TILE", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_ops_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k", sel], env=env, capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(HERE))
+    tail = r.stdout[-1500:]
+    assert r.returncode == 0, tail + r.stderr[-1500:]
+    assert " passed" in tail and "failed" not in tail, tail
