@@ -126,7 +126,7 @@ def translate(text, name):
 
 def _sources():
     files = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")) + ["capi.cpp"]
-    return [os.path.join(CSRC, f) for f in files]
+    return [os.path.join(CSRC, f) for f in files] + [os.path.join(HERE, "selftest_kernels.cpp")]
 
 
 def _stamp():
