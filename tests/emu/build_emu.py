@@ -135,6 +135,11 @@ def _stamp():
                            os.path.join(HERE, "emu.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h"), os.path.abspath(__file__)]:
         with open(p, "rb") as f:
             h.update(f.read())
+    try:      # -march=native: a library built on another host CPU must not be reused
+        with open("/proc/cpuinfo") as f:
+            h.update("".join(sorted({ln for ln in f if ln.startswith(("model name", "flags"))})).encode())
+    except OSError:
+        pass
     return h.hexdigest()
 
 
