@@ -1,6 +1,8 @@
 // Host-side SIMT emulator: scheduler, cross-lane operations, LDS-DMA queue, guarded allocations.  See emu.h.
 #include "emu.h"
 
+#include <cxxabi.h>
+#include <dlfcn.h>
 #include <execinfo.h>
 #include <signal.h>
 #include <sys/mman.h>
@@ -11,7 +13,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <algorithm>
 #include <map>
+#include <string>
 #include <vector>
 
 namespace emu {
@@ -404,6 +408,9 @@ void ensure_fibers(int n) {
 
 }  // namespace
 
+static std::map<const void*, long long> g_hist;
+void note_launch(const void* kernel) { g_hist[kernel]++; }
+
 const LaneInfo& me() { return g_cur->info; }
 unsigned char* dyn_smem() { return g_smem; }
 uint64_t clock_ticks() { return ++g_clock; }
@@ -498,6 +505,30 @@ void emu_free_guarded(void* p) {
 }
 
 long long emu_launch_count() { return emu::g_launches; }
+
+long long emu_launch_histogram(char* buf, long long cap, int reset) {
+  std::vector<std::pair<long long, std::string>> rows;
+  for (const auto& kv : emu::g_hist) {
+    Dl_info info{};
+    std::string name = "?";
+    if (dladdr(kv.first, &info) && info.dli_sname) {
+      int status = 0;
+      char* dm = abi::__cxa_demangle(info.dli_sname, nullptr, nullptr, &status);
+      name = status == 0 && dm ? dm : info.dli_sname;
+      free(dm);
+    }
+    rows.emplace_back(kv.second, name);
+  }
+  std::sort(rows.begin(), rows.end(), [](const auto& a, const auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+  std::string text;
+  for (const auto& r : rows) text += std::to_string(r.first) + "\t" + r.second + "\n";
+  if (reset) emu::g_hist.clear();
+  if (cap <= 0) return 0;
+  const long long n = std::min<long long>((long long)text.size(), cap - 1);
+  memcpy(buf, text.data(), n);
+  buf[n] = 0;
+  return n;
+}
 long long emu_waveop_count() { return emu::g_waveops; }
 
 }

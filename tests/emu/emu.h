@@ -52,6 +52,7 @@ void barrier();                                                       // s_barri
 void dma_to_lds(void* lds_dst, const void* src_or_null, int bytes);   // one lane's share of a buffer_load ... lds
 void wait_vmcnt(int n);                                               // at most n of this lane's LDS-DMAs stay in flight
 void launch(dim3 grid, dim3 block, size_t dyn_smem_bytes, const std::function<void()>& body);
+void note_launch(const void* kernel);      // per-kernel launch histogram (emu_launch_histogram)
 uint64_t clock_ticks();
 
 }  // namespace emu
@@ -64,5 +65,8 @@ void emu_set_dma_mode(int lazy);
 void* emu_alloc_guarded(size_t bytes);
 void emu_free_guarded(void* p);
 long long emu_launch_count();
+// "count<TAB>demangled kernel name" lines of every kernel launched since the last reset, most frequent first; returns the
+// number of bytes written (the text is truncated to cap - 1 bytes and NUL-terminated).  reset != 0 clears the histogram.
+long long emu_launch_histogram(char* buf, long long cap, int reset);
 long long emu_waveop_count();
 }

@@ -247,6 +247,7 @@ static inline hipError_t hipGetSymbolAddress(void** p, T& sym) { *p = (void*)&sy
 
 template <typename K, typename... Args>
 static inline void emu_launch_kernel(K kern, dim3 grid, dim3 block, size_t smem, hipStream_t, Args... args) {
+  ::emu::note_launch(reinterpret_cast<const void*>(kern));
   ::emu::launch(grid, block, smem, [&] { kern(args...); });
 }
 #define hipLaunchKernelGGL(kern, grid, block, smem, stream, ...) \
