@@ -162,10 +162,10 @@ def hbm_kernel_rows(dev, sched, ops, iters=20, warm=3):
     a = torch.randn(32, 64, 64, 320, device=dev, generator=g).bfloat16()
     gam, bet = torch.ones(320, device=dev), torch.zeros(320, device=dev)
     us = timeit(lambda: ops.groupnorm(a, gam, bet, 32, silu=True))
-    rows.append(("gn_fused_kernel (GroupNorm + SiLU, one read + one write)", list(a.shape), 2 * 2 * a.numel(), us))
+    rows.append(("ldm_groupnorm + SiLU (one-kernel form at this shape: one read + one write)", list(a.shape), 2 * 2 * a.numel(), us))
     a3 = a.view(32, 4096, 320)
     us = timeit(lambda: ops.layernorm(a3, gam, bet))
-    rows.append(("layernorm_kernel", list(a3.shape), 2 * 2 * a3.numel(), us))
+    rows.append(("ldm_layernorm", list(a3.shape), 2 * 2 * a3.numel(), us))
     return [{"kernel": k, "shape": sh, "algorithmic_bytes": b, "us_per_launch": round(u, 2), "GB_per_s": round(b / u / 1e3, 1),
              "frac_of_hbm_peak": round(b / u / 1e3 / 8000.0, 3)} for k, sh, b, u in rows]
 
