@@ -1,0 +1,47 @@
+"""Static invariants of the built gfx950 code objects (tools/isa_audit.py; no GPU): the hot kernels of the path must not spill
+to scratch and must not contain a waterfall loop (a buffer descriptor the compiler could not prove wave-uniform -- in round 2 a
+clamped `bytes - offset` put one around every K/V fetch of the attention kernels: +17 % instructions, found only in the
+disassembly), and each keeps within the register budget its launch bounds assume."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import isa_audit  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rows():
+    if not os.path.isdir(isa_audit.BUILD) or not any(f.endswith(".hip.o") for f in os.listdir(isa_audit.BUILD)):
+        pytest.skip("objects not built (make -C latent-diffusion_amd/csrc)")
+    return isa_audit.all_rows()
+
+
+HOT = ("conv_gemm_bf16_kernel<", "attention_bf16_kernel<40>", "attention_bf16_kernel<64>", "attention_bf16_kernel<80>",
+       "attention32_bf16_kernel<40>", "attn_bwd_dq_kernel<40>", "attn_bwd_dkv_kernel<40>", "attn_bwd_dq_kernel<80>",
+       "attn_bwd_dkv_kernel<80>", "conv_wgrad_bf16_v2_kernel<", "gn_fused_kernel<", "layernorm_kernel<", "ddpm_step_kernel<",
+       "ddpm_add_noise_kernel<")
+
+
+def test_hot_kernels_have_no_spills_and_no_waterfall_loops(rows):
+    hot = [r for r in rows if r["kernel"].startswith(HOT)]
+    assert len(hot) >= 30, [r["kernel"] for r in hot]
+    for r in hot:
+        assert r["scratch"] == 0 and r["scratch_ops"] == 0, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
+        assert r["waterfall"] == 0, (r["kernel"], "waterfall loops", r["waterfall"])
+
+
+def test_register_budgets_match_the_launch_bounds(rows):
+    by = {r["kernel"]: r for r in rows}
+    # 512-thread GEMM tiles: one workgroup per CU, two waves per SIMD -> at most 256 registers, no AGPR spill traffic
+    for k in ("conv_gemm_bf16_kernel<256, 160, 64, 4, 2, 3>", "conv_gemm_bf16_kernel<256, 128, 64, 4, 2, 3>"):
+        assert by[k]["vgpr"] <= 256 and by[k]["accvgpr"] == 0, (k, by[k]["vgpr"])
+    # d = 40 attention: two 256-thread workgroups per CU -> 2 waves per SIMD
+    for k in ("attention32_bf16_kernel<40>", "attention_bf16_kernel<40>"):
+        assert by[k]["vgpr"] <= 256 and by[k]["agpr"] == 0, (k, by[k]["vgpr"], by[k]["agpr"])
+    # the matrix-core instruction count of the d = 40 pipelined kernel: 14 per key tile (6 Q K^T + 8 P V), 6 tile bodies
+    # (peeled first product, two unrolled steps in the loop, three tail steps) -- a change here is a change of the schedule
+    assert by["attention32_bf16_kernel<40>"]["mfma"] == 92
