@@ -17,7 +17,9 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 def code_object(obj, tmp):
     fat = os.path.join(tmp, "fat.bin")
     hsaco = os.path.join(tmp, "k.hsaco")
-    if subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj], capture_output=True).returncode:
+    # an explicit output file: without one llvm-objcopy rewrites its INPUT in place (and make then relinks the library)
+    if subprocess.run([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj, os.path.join(tmp, "copy.o")],
+                      capture_output=True).returncode:
         return None
     r = subprocess.run([f"{LLVM}/clang-offload-bundler", "--type=o", "--unbundle", f"--input={fat}",
                         "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={hsaco}"], capture_output=True)
