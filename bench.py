@@ -13,10 +13,15 @@ Other modes (same launch contract, same JSON schema):
   --train    BASELINE.json configs[3]: the reference's train step (add_noise -> bf16 forward -> MSE -> backward with the
              bucketed RCCL gradient all-reduce -> clip -> AdamW), 32 latents per GPU; value in img/s; "scaling": "weak".
 
+Passes (default and --strong modes): `value` / `ms_per_step` come from K steps with NO per-launch instrumentation; the
+`roofline` object comes from a SECOND pass over the same K steps with two HIP events around every GEMM launch (that pass's
+own ms_per_step is printed as config.ms_per_step_instrumented_pass); the LayerNorm-fold A/B (N=1) repeats both passes with
+the fold switched the other way, so the two variants are timed with identical instrumentation.
+
 Printed JSON (rank 0, one line) also carries
   roofline      the dominant kernel (bf16 implicit-GEMM conv/linear; in --train possibly the weight-gradient kernel):
                 algorithmic FLOPs per launch / its average launch duration, measured with HIP events on the launch
-                stream inside the timed region, against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch from the
+                stream over the instrumented pass, against the dense bf16 MFMA peak; `traffic` = HBM bytes per launch from the
                 rocprofv3 --pmc passes recorded in bench_pmc_traffic.json (tools/profile_bench.sh writes it), reported only
                 while the kernel sources still hash to what was profiled -- else null;
   cpu_baseline  the CPU oracle (oracle/unet_ref.py + scheduler_ref.py: a port, not the product) timed on this
@@ -131,19 +136,21 @@ def roofline_from_log(log, elapsed, workload_key):
     return roof, gemm_time / elapsed
 
 
-def hbm_kernel_rows(dev, sched, ops, iters=20, warm=3):
+def hbm_kernel_rows(dev, sched, ops, iters=24, warm=3):
     """Achieved HBM rate of the memory-bound kernels of the path at sizes where a rate means something (the step itself runs
     them at launch-bound sizes): scheduler step and add_noise on (256, 4, 64, 64) float32 latents -- BASELINE.json configs[2]'s
-    whole job in one launch -- GroupNorm + SiLU and LayerNorm on the 64x64 level's activation (32 x 4096 x 320, bf16).  HIP events
-    on torch's current stream, the stream these kernels are launched on; algorithmic bytes = every operand read once + every
-    result written once.  Outside every timed region."""
-    def timeit(fn):
-        for _ in range(warm):
-            fn()
+    whole job in one launch -- GroupNorm + SiLU and LayerNorm on the 64x64 level's activation (32 x 4096 x 320, bf16).  Every
+    launch works on its own set of operand buffers and the sets of one row add up to more than 512 MiB, twice the 256 MiB
+    Infinity Cache, so no launch finds its operands (or the lines its results go to) in a cache: these are DRAM rates.  HIP
+    events on torch's current stream, the stream these kernels are launched on; algorithmic bytes = every operand read once +
+    every result written once.  Outside every timed region."""
+    def timeit(fns):
+        for f in fns[:warm]:
+            f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fns[i % len(fns)]()
         e1.record()
         torch.cuda.synchronize(dev)
         return e0.elapsed_time(e1) * 1e3 / iters       # microseconds per launch
@@ -151,23 +158,32 @@ def hbm_kernel_rows(dev, sched, ops, iters=20, warm=3):
     rows = []
     g = torch.Generator(device=dev).manual_seed(7)
     shape = (256, 4, 64, 64)
-    eps, x, noise = (torch.randn(shape, device=dev, generator=g) for _ in range(3))
-    n = eps.numel()
+    nset = 12                                          # 12 sets x 3 inputs x 16.8 MB = 604 MB read per sweep
+    sets = [tuple(torch.randn(shape, device=dev, generator=g) for _ in range(3)) for _ in range(nset)]
+    n = sets[0][0].numel()
     t_mid = sched.timesteps[len(sched.timesteps) // 2]
-    us = timeit(lambda: sched.step(eps, t_mid, x, noise=noise))
-    rows.append(("ddpm_step_kernel (eps, x_t, noise -> prev, x0)", list(shape), 5 * 4 * n, us))
+    us = timeit([(lambda s=s: sched.step(s[0], t_mid, s[1], noise=s[2])) for s in sets])
+    rows.append(("ddpm_step_kernel (eps, x_t, noise -> prev, x0)", list(shape), 5 * 4 * n, us, nset * 3 * 4 * n))
     tt = torch.randint(0, 1000, (shape[0],), device=dev, generator=g)
-    us = timeit(lambda: sched.add_noise(x, noise, tt))
-    rows.append(("ddpm_add_noise_kernel (x0, noise -> noisy)", list(shape), 3 * 4 * n, us))
-    a = torch.randn(32, 64, 64, 320, device=dev, generator=g).bfloat16()
+    us = timeit([(lambda s=s: sched.add_noise(s[1], s[2], tt)) for s in sets])
+    rows.append(("ddpm_add_noise_kernel (x0, noise -> noisy)", list(shape), 3 * 4 * n, us, nset * 2 * 4 * n))
+    del sets
+    nact = 8                                           # 8 x 83.9 MB = 671 MB of distinct bf16 activations
+    acts = [torch.randn(32, 64, 64, 320, device=dev, generator=g).bfloat16() for _ in range(nact)]
     gam, bet = torch.ones(320, device=dev), torch.zeros(320, device=dev)
-    us = timeit(lambda: ops.groupnorm(a, gam, bet, 32, silu=True))
-    rows.append(("ldm_groupnorm + SiLU (one-kernel form at this shape: one read + one write)", list(a.shape), 2 * 2 * a.numel(), us))
-    a3 = a.view(32, 4096, 320)
-    us = timeit(lambda: ops.layernorm(a3, gam, bet))
-    rows.append(("ldm_layernorm", list(a3.shape), 2 * 2 * a3.numel(), us))
+    us = timeit([(lambda a=a: ops.groupnorm(a, gam, bet, 32, silu=True)) for a in acts])
+    rows.append(("ldm_groupnorm + SiLU (one-kernel form at this shape: one read + one write)", list(acts[0].shape),
+                 2 * 2 * acts[0].numel(), us, nact * 2 * acts[0].numel()))
+    us = timeit([(lambda a=a: ops.layernorm(a.view(32, 4096, 320), gam, bet)) for a in acts])
+    rows.append(("ldm_layernorm", [32, 4096, 320], 2 * 2 * acts[0].numel(), us, nact * 2 * acts[0].numel()))
     return [{"kernel": k, "shape": sh, "algorithmic_bytes": b, "us_per_launch": round(u, 2), "GB_per_s": round(b / u / 1e3, 1),
-             "frac_of_hbm_peak": round(b / u / 1e3 / 8000.0, 3)} for k, sh, b, u in rows]
+             "frac_of_hbm_peak": round(b / u / 1e3 / 8000.0, 3), "distinct_input_MB_rotated": round(rot / 1e6)}
+            for k, sh, b, u, rot in rows]
+
+
+def _unet_mod():
+    from ldm import unet
+    return unet
 
 
 def main():
@@ -180,6 +196,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="configs[2]: 256 latents sharded over the ranks, strong scaling")
     ap.add_argument("--train", action="store_true", help="configs[3]: the training step, 32 latents per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--plain-only", action="store_true",
+                    help="profiler runs (tools/profile_bench.sh): only the un-instrumented pass -- no event-log pass, no A/B legs, no roofline")
     args = ap.parse_args()
     if args.strong and args.train:
         raise SystemExit("--strong and --train are exclusive")
@@ -267,19 +285,29 @@ def main():
             opt.zero_grad(set_to_none=True)
             return loss
 
-        for _ in range(args.warmup):
-            loss = train_step()
-        ops.set_launch_log(log)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = train_step()
-        barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
-        ops.set_launch_log(None)
+        def timed_pass(instrument, warm):
+            for _ in range(warm):
+                loss = train_step()
+            ops.set_launch_log(instrument)
+            try:
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    loss = train_step()
+                barrier()
+                dt = time.perf_counter() - t0
+            finally:
+                ops.set_launch_log(None)
+            return dt, loss
+
+        elapsed, loss = timed_pass(None, args.warmup)     # `value`: no per-launch instrumentation
+        elapsed = max_over_ranks(elapsed)
+        elapsed_log, _ = timed_pass(log, 1)               # `roofline`: the same steps with HIP events around every GEMM / wgrad launch
         assert torch.isfinite(loss), "non-finite loss"
         if rank == 0:
-            roof, share = roofline_from_log(log, elapsed, f"train_b{B}_l{LAT}")
+            roof, share = roofline_from_log(log, elapsed_log, f"train_b{B}_l{LAT}")
+            roof["measured_in"] = ("a second pass over the same steps with two HIP events around every GEMM / weight-gradient "
+                                   "launch; `value` is from the un-instrumented pass")
             flops = 3.0 * flops_per_image * B
             out = {
                 "metric": f"UNet training img/s at {LAT}x{LAT} latents (noise-prediction MSE, bf16 compute / fp32 master, AdamW)",
@@ -293,7 +321,8 @@ def main():
                            "parallelism": f"data parallel x{world}, bucketed gradient all-reduce overlapped with the backward",
                            "collectives_per_backward": model.reducer.launched,
                            "frac_of_mfma_peak_at_3x_forward_flops": round(flops / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
-                           "gemm_kernel_share_of_step": round(share, 3),
+                           "ms_per_step_instrumented_pass": round(1e3 * elapsed_log / args.steps, 3),
+                           "gemm_kernel_share_of_instrumented_step": round(share, 3),
                            "peak_device_memory_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
                            "loss": round(float(loss), 5)},
                 "roofline": roof}
@@ -324,24 +353,46 @@ def main():
                 last = sched.step(eps, t, lat0[s], noise=noise[s]).prev_sample  # fp32 scheduler update, fused kernel
             return last
 
-        with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
-            for i in range(args.warmup):
-                lat = one_step(i)
-            ops.set_launch_log(log)
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(args.steps):
-                lat = one_step(i)
-            barrier()
-            elapsed = time.perf_counter() - t0
-            ops.set_launch_log(None)
+        def timed_pass(instrument):
+            """W warm-up steps, then K steps bracketed by barrier + synchronize.  instrument: a list that receives two HIP
+            events per GEMM launch (ops.set_launch_log) -- the roofline pass; None -- the pass `value` is taken from."""
+            nonlocal lat
+            with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
+                for i in range(args.warmup):
+                    lat = one_step(i)
+                ops.set_launch_log(instrument)
+                try:
+                    barrier()
+                    t0 = time.perf_counter()
+                    for i in range(args.steps):
+                        lat = one_step(i)
+                    barrier()
+                    dt = time.perf_counter() - t0
+                finally:
+                    ops.set_launch_log(None)
+            return dt
+
+        lat = None
+        elapsed = timed_pass(None)                   # `value`: no per-launch instrumentation inside the timed region
         assert torch.isfinite(lat).all(), "non-finite latents"
         elapsed = max_over_ranks(elapsed)
+        if args.plain_only:
+            os.environ["LDM_BENCH_AB"] = "0"
+            elapsed_log = float("nan")
+        else:
+            elapsed_log = timed_pass(log)            # `roofline`: the same steps once more with the event log on
+        fold_on = bool(ops._ln_fold_checked) and all(ops._ln_fold_checked.values()) and _unet_mod()._LN_FOLD
         if rank == 0:
             ms = 1e3 * elapsed / args.steps
             total = STRONG_LATENTS if args.strong else world * B
             headline = LAT == 64 and ((not args.strong and B == BATCH) or args.strong)
-            roof, share = roofline_from_log(log, elapsed, f"{'strong' if args.strong else 'fwd'}_b{min(B, STRONG_MICRO_BATCH) if args.strong else B}_l{LAT}")
+            wkey = f"{'strong' if args.strong else 'fwd'}_b{min(B, STRONG_MICRO_BATCH) if args.strong else B}_l{LAT}"
+            if args.plain_only:
+                roof, share = None, float("nan")
+            else:
+                roof, share = roofline_from_log(log, elapsed_log, wkey)
+                roof["measured_in"] = ("a second pass over the same steps with two HIP events around every GEMM launch; "
+                                       "`value` is from the un-instrumented pass")
             if args.strong:
                 workload = (f"SD-1.5-shaped UNet (859.5M params, random init) bf16 denoise + DDPM scheduler step over {STRONG_LATENTS} latents of "
                             f"4x{LAT}x{LAT} + 77x768 context, sharded {STRONG_LATENTS}/{world} per GPU in micro-batches of "
@@ -359,40 +410,47 @@ def main():
                            "parallelism": f"batch-sharded x{world}, no data-path collective",
                            "end_to_end_tflops_per_gpu": round(flops_per_image * total / world / (elapsed / args.steps) / 1e12, 1),
                            "end_to_end_frac_of_mfma_peak": round(flops_per_image * total / world / (elapsed / args.steps) / MFMA_BF16_DENSE_PEAK, 4),
-                           "gemm_kernel_share_of_step": round(share, 3),
-                           "layernorm_fold_active": bool(ops._ln_fold_checked) and all(ops._ln_fold_checked.values())},
+                           "ms_per_step_instrumented_pass": round(1e3 * elapsed_log / args.steps, 3),
+                           "gemm_kernel_share_of_instrumented_step": round(share, 3),
+                           "layernorm_fold_active": fold_on},
                 "roofline": roof}
+            if args.plain_only:
+                out["config"]["ms_per_step_instrumented_pass"] = out["config"]["gemm_kernel_share_of_instrumented_step"] = None
             if world == 1 and not args.no_cpu_baseline and LAT == 64 and not args.strong:
                 out["cpu_baseline"] = cpu_baseline()
-        if world == 1 and not args.strong and not args.train and out is not None and LAT == 64 \
-                and os.environ.get("LDM_BENCH_AB", "1") != "0":
+        side = world == 1 and not args.strong and out is not None and os.environ.get("LDM_BENCH_AB", "1") != "0"
+        if side and LAT == 64:
             try:
                 with torch.no_grad():
                     out["config"]["hbm_kernels"] = hbm_kernel_rows(dev, sched, ops)
             except Exception as exc:   # a side measurement never costs the headline line
                 out["config"]["hbm_kernels"] = f"failed: {type(exc).__name__}: {exc}"
-        # A/B inside the same process and on the same device (devices of the pool differ by up to 10 %): the same steps once more
-        # with the LayerNorm fold switched off (separate LayerNorm kernels).  Outside the timed region of `value`; one rank only.
-        if world == 1 and not args.strong and out is not None and out["config"].get("layernorm_fold_active") \
-                and os.environ.get("LDM_BENCH_AB", "1") != "0":
-            from ldm import unet as _unet
-            _unet._LN_FOLD = False
-            net.invalidate_packed_weights()
+        # A/B inside the same process and on the same device (devices of the pool differ by up to 10 %): both passes once
+        # more with the LayerNorm fold switched the other way -- same warm-up, same steps, same instrumentation per pass.
+        if side and ops.ln_fold_supported(320, torch.bfloat16):
+            um = _unet_mod()
+            was = um._LN_FOLD
+            ab = {}
             try:
-                with torch.inference_mode(), torch.autocast("cuda", dtype=torch.bfloat16):
-                    for i in range(args.warmup):
-                        lat = one_step(i)
-                    barrier()
-                    t0 = time.perf_counter()
-                    for i in range(args.steps):
-                        lat = one_step(i)
-                    barrier()
-                    out["config"]["ms_per_step_without_layernorm_fold"] = round(1e3 * (time.perf_counter() - t0) / args.steps, 3)
-            except Exception as exc:
-                out["config"]["ms_per_step_without_layernorm_fold"] = f"failed: {type(exc).__name__}: {exc}"
-            finally:
-                _unet._LN_FOLD = True
+                um._LN_FOLD = not fold_on
                 net.invalidate_packed_weights()
+                dt_plain = timed_pass(None)
+                other_log = []
+                dt_log = timed_pass(other_log)
+                other_on = bool(ops._ln_fold_checked) and all(ops._ln_fold_checked.values()) and um._LN_FOLD
+                roof_o, _ = roofline_from_log(other_log, dt_log, "ab")
+                ab = {"fold": other_on, "ms_per_step": round(1e3 * dt_plain / args.steps, 3),
+                      "ms_per_step_instrumented_pass": round(1e3 * dt_log / args.steps, 3),
+                      "gemm_kernels": roof_o["all_gemm_kernels"]}
+            except Exception as exc:
+                ab = {"failed": f"{type(exc).__name__}: {exc}"}
+            finally:
+                um._LN_FOLD = was
+                net.invalidate_packed_weights()
+            out["config"]["layernorm_fold_ab"] = {
+                "this_line": {"fold": fold_on, "ms_per_step": out["ms_per_step"],
+                              "ms_per_step_instrumented_pass": out["config"]["ms_per_step_instrumented_pass"]},
+                "other": ab}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

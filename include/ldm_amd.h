@@ -233,7 +233,9 @@ int ldm_groupnorm(const void* a0, const void* a1, int c0, int c1, int dtype, int
  * The call makes no hipMalloc / hipFree and calls no allocating routine.  LDM_EINVAL if batch * groups exceeds
  * LDM_GROUPNORM_NOALLOC_MAX_FLOATS / 128 (= 8192; e.g. 256 samples x 32 groups).  All calls on one GPU share that GPU's
  * array: calls that overlap on one GPU (two streams) race; calls ordered on one stream do not.  Nothing in the array has to be
- * zero on entry (every word read is written earlier in the same call). */
+ * zero on entry (every word read is written earlier in the same call).  Graph capture: the FIRST call on a device looks the
+ * array's address up (hipGetSymbolAddress, not a stream operation) and is refused with LDM_EINVAL while `stream` is capturing --
+ * make one ordinary call per device before capturing; every later call is capturable. */
 #define LDM_GROUPNORM_NOALLOC_MAX_FLOATS (1 << 20)
 int ldm_groupnorm_noalloc(const void* a0, const void* a1, int c0, int c1, int dtype, int batch, int hw, int groups, float eps,
                           const float* gamma, const float* beta, int silu, void* out, float* stats, void* stream);

@@ -41,6 +41,8 @@ struct ConvGemmParams {
   int ln_nseg;
   const float* ln_s1;     //   [N]: sum_k W'[n][k] of the gamma-scaled filter this call multiplies with
   float ln_eps;
+  int wt;           // write-through (sc1) stores for the output / the split-K partial sums (common.h store8_wt)
+  unsigned out_bytes;
   int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
   float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
@@ -517,8 +519,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             }
             if (has_res) add_bf16x8(v, rres[ps]);
           }
-          if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
-          else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+          if (p.wt) {
+            if (out_f32) store8_wt(static_cast<float*>(outp), p.out_bytes, (size_t)m * nout + ocol[ps], v);
+            else store8_wt(static_cast<bf16_t*>(outp), p.out_bytes, (size_t)m * nout + ocol[ps], v);
+          } else {
+            if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
+            else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+          }
           if (want_stats) {
             float sx = 0.f, sq = 0.f;
 #pragma unroll
@@ -643,8 +650,13 @@ splitk_reduce_kernel(const ConvGemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += t[e];
   }
-  if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * p.N + n, v);
-  else store8(static_cast<bf16_t*>(p.out) + (size_t)m * p.N + n, v);
+  if (p.wt) {
+    if (p.out_f32) store8_wt(static_cast<float*>(p.out), p.out_bytes, (size_t)m * p.N + n, v);
+    else store8_wt(static_cast<bf16_t*>(p.out), p.out_bytes, (size_t)m * p.N + n, v);
+  } else {
+    if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * p.N + n, v);
+    else store8(static_cast<bf16_t*>(p.out) + (size_t)m * p.N + n, v);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- fp32
@@ -813,6 +825,9 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(64 * WM * WN), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(bf16)");
   if (p.splits > 1) {
+    const long long fb = (long long)p.M * p.N * (p.out_f32 ? 4 : 2);
+    p.wt = p.wt && fb < (1LL << 32) ? 1 : 0;
+    p.out_bytes = (unsigned)fb;
     const long long chunks = (long long)p.M * (p.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, p);
     LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(split-K fold)");
@@ -930,6 +945,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.residual = d->residual; p.out = d->out;
   p.out_f32 = d->out_dtype == LDM_F32;
   p.vec_epilogue = 0;
+  p.wt = 0;
+  p.out_bytes = 0;
   p.splits = 1;
   p.partial = nullptr;
   p.rowstats = (epi & LDM_EPI_ROWSTATS) ? d->rowstats : nullptr;
@@ -950,6 +967,11 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
       LDM_REQUIRE(d->ln_stats && d->ln_colsum && d->ln_segments >= 1 && d->ln_segments <= 64 && d->ksize == 1 && d->c1 == 0 &&
                       d->stride == 1 && !d->upsample && d->ln_eps > 0.f && (reinterpret_cast<uintptr_t>(d->ln_stats) & 7) == 0,
                   "ldm_conv_gemm: LDM_EPI_LNFOLD needs ln_stats / ln_colsum / ln_segments and a plain (1x1, single-source) layer");
+    // the statistics are per 80-column segment of the tensor this call reads as A: any other count would read past the
+    // statistics buffer (or normalise with another layer's sums)
+    if (epi & LDM_EPI_LNFOLD)
+      LDM_REQUIRE(d->ln_segments * 80 == d->c0, "ldm_conv_gemm: LDM_EPI_LNFOLD: %d segments of 80 columns do not cover c0 = %d",
+                  d->ln_segments, d->c0);
   }
 
   if (d->dtype == LDM_F32) {
@@ -987,6 +1009,14 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
                      !(epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD));       // the split-K fold kernel knows neither
   pick_tile_bf16(p, glu, ws_ok ? d->workspace_bytes : 0, bm, bn, bk, p.splits);
   p.partial = static_cast<float*>(d->workspace);
+  {
+    // write-through stores address the output through a 32-bit buffer descriptor: the tensor (one split's partial sums) must
+    // stay under 4 GiB; the split-K fold kernel writes the real output, whose size is set before its launch
+    const int nout = glu ? p.N / 2 : p.N;
+    const long long ob = p.splits > 1 ? (long long)p.M * p.N * 4 : (long long)p.M * nout * (p.out_f32 ? 4 : 2);
+    p.wt = wt_stores_enabled() && p.vec_epilogue && ob < (1LL << 32) ? 1 : 0;
+    p.out_bytes = (unsigned)ob;
+  }
   // row statistics are laid out per 80-column wave tile of a BN = 160 tile (rowstats[m][n / 80][2]): any other tile would
   // write a different segment count than the caller allocated
   LDM_REQUIRE(!(epi & LDM_EPI_ROWSTATS) || (bn == 160 && bk == 64),

@@ -583,7 +583,7 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 float* g_scratch_ptr[kMaxDevices] = {};
 
-int scratch_for_current_device(float** out) {
+int scratch_for_current_device(hipStream_t stream, float** out) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
@@ -592,6 +592,13 @@ int scratch_for_current_device(float** out) {
   }
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (g_scratch_ptr[dev] == nullptr) {
+    // The symbol lookup may load the code object: not a stream operation, so it must not happen while `stream` is being
+    // captured into a graph.  Callers that capture make one ordinary call per device first (include/ldm_amd.h).
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      set_error("ldm_groupnorm_noalloc: first call on device %d is under stream capture; call it once outside the capture first", dev);
+      return LDM_EINVAL;
+    }
     void* ptr = nullptr;
     e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
     if (e != hipSuccess || ptr == nullptr) {
@@ -616,7 +623,7 @@ extern "C" int ldm_groupnorm_noalloc(const void* a0, const void* a1, int c0, int
               "(batch * groups <= %d); use ldm_groupnorm with a caller workspace",
               batch, groups, need, (int)LDM_GROUPNORM_NOALLOC_MAX_FLOATS, (int)(LDM_GROUPNORM_NOALLOC_MAX_FLOATS / (2 * GN_MAX_SLABS)));
   float* ws = nullptr;
-  const int rc = scratch_for_current_device(&ws);
+  const int rc = scratch_for_current_device((hipStream_t)stream, &ws);
   if (rc) return rc;
   // Nothing in the buffer has to start at zero: gn_partial_kernel writes every (sample, slab, group) pair that
   // gn_finalize_kernel reads in the same call.

@@ -39,6 +39,40 @@ def _ptr(t: Optional[torch.Tensor]) -> int:
     return 0 if t is None else t.data_ptr()
 
 
+# The kernels read their side operands (norm affine parameters, biases, raw filters, statistics) as dense float32 arrays of a
+# length implied by the other arguments, and their activations in ONE dtype.  A tensor of another dtype or length would be read
+# past its end (round 2's GPU fault: a bf16 bias read as float32), so every front end checks before it hands out a pointer.
+def _f32_dense(what: str, t: Optional[torch.Tensor], numel: int) -> None:
+    if t is None:
+        return
+    if t.dtype != torch.float32 or t.numel() != numel or not t.is_contiguous():
+        raise TypeError(f"{what} must be a contiguous float32 tensor of {numel} elements "
+                        f"(got {t.dtype}, shape {tuple(t.shape)}, contiguous={t.is_contiguous()})")
+
+
+def _same_dtype_dense(what: str, ref: torch.Tensor, *others: Optional[torch.Tensor]) -> None:
+    if not ref.is_contiguous():
+        raise ValueError(f"{what}: operands must be contiguous")
+    for t in others:
+        if t is None:
+            continue
+        if t.dtype != ref.dtype:
+            raise TypeError(f"{what}: operands must share one dtype (got {ref.dtype} and {t.dtype})")
+        if not t.is_contiguous():
+            raise ValueError(f"{what}: operands must be contiguous")
+
+
+def _rows3(what: str, t: torch.Tensor, dtype: torch.dtype, batch: int, rows: int, cols: int) -> None:
+    """A (B, L, C) operand of the attention kernels: unit column stride, rows `stride(1)` apart, samples L rows apart (a dense
+    tensor or a column slice of one, e.g. q / k|v inside the fused q|k|v buffer)."""
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: dtype {t.dtype} does not match the query's {dtype}")
+    if t.dim() != 3 or tuple(t.shape) != (batch, rows, cols):
+        raise ValueError(f"{what}: expected shape {(batch, rows, cols)}, got {tuple(t.shape)}")
+    if t.numel() and (t.stride(2) != 1 or t.stride(1) < cols or (batch > 1 and t.stride(0) != rows * t.stride(1))):
+        raise ValueError(f"{what}: must be a row-strided (B, L, C) view with unit column stride (strides {t.stride()})")
+
+
 def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) -> torch.Tensor:
     """float32 [O, I, kh, kw] or [O, I]  ->  [O', kh*kw*I] K-contiguous filter in `dtype`."""
     _gpu(w)
@@ -150,6 +184,12 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
     for name_, t_ in (("rowvec", rowvec), ("residual", residual), ("a1", a1), ("w", w)):
         if t_ is not None and t_.dtype != a0.dtype:
             raise TypeError(f"conv_gemm: {name_} must have the activation dtype {a0.dtype} (got {t_.dtype})")
+    if w.dim() != 2 or not w.is_contiguous():
+        raise ValueError("conv_gemm: the packed filter must be a contiguous (N, K) matrix")
+    if residual is not None and (not residual.is_contiguous() or residual.numel() != batch * hout * wout * n or glu):
+        raise ValueError(f"conv_gemm: residual must be a contiguous tensor of the output's {batch * hout * wout} x {n} elements (no GLU)")
+    if rowvec is not None and (rowvec.dim() != 2 or rowvec.shape != (batch, n) or rowvec.stride(1) != 1):
+        raise ValueError(f"conv_gemm: rowvec must be a (batch, N) = ({batch}, {n}) view with unit column stride, got {tuple(rowvec.shape)}")
     odt = out_dtype or a0.dtype
     nout = n // 2 if glu else n
     out = torch.empty((*out_lead, nout), dtype=odt, device=a0.device)
@@ -168,8 +208,12 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
         ln_stats, ln_colsum, ln_eps = ln
         _gpu(ln_stats, ln_colsum)
         if ln_stats.dtype != torch.float32 or ln_stats.dim() != 3 or ln_stats.shape[0] != batch * hout * wout or \
-                ln_stats.shape[2] != 2 or not ln_stats.is_contiguous() or ln_colsum.numel() != n or ln_colsum.dtype != torch.float32:
-            raise ValueError("conv_gemm(ln=...): stats must be float32 (M, segments, 2), colsum float32 (N,)")
+                ln_stats.shape[2] != 2 or not ln_stats.is_contiguous():
+            raise ValueError("conv_gemm(ln=...): stats must be contiguous float32 (M, segments, 2)")
+        if ln_stats.shape[1] * 80 != c0 or c1 or ksize != 1:
+            raise ValueError(f"conv_gemm(ln=...): {ln_stats.shape[1]} statistics segments of 80 columns do not cover the {c0} "
+                             "channels of a0 (the statistics must come from the GEMM that wrote a0)")
+        _f32_dense("conv_gemm(ln=...): colsum", ln_colsum, n)
         d.epilogue |= _lib.EPI_LNFOLD
         d.ln_stats, d.ln_colsum, d.ln_segments, d.ln_eps = ln_stats.data_ptr(), ln_colsum.data_ptr(), ln_stats.shape[1], float(ln_eps)
     if a0.dtype == torch.bfloat16 and batch * hout * wout <= _SPLITK_MAX_ROWS and not rowstats and ln is None:
@@ -312,6 +356,9 @@ def sum2x2(x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Te
     B, H, W, Cc = x.shape
     if H % 2 or W % 2 or Cc % 8 or not x.is_contiguous():
         raise ValueError("sum2x2: contiguous (B, even H, even W, C % 8 == 0) input")
+    if residual is not None and (residual.dtype != x.dtype or tuple(residual.shape) != (B, H // 2, W // 2, Cc)
+                                 or not residual.is_contiguous()):
+        raise ValueError("sum2x2: residual must be a contiguous tensor of the output's shape and dtype")
     out = torch.empty((B, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_sum2x2(x.data_ptr(), _ptr(residual), out.data_ptr(), dt_code(x.dtype), B, H // 2, W // 2, Cc,
@@ -424,33 +471,18 @@ def _gn_workspace(device, batch: int, groups: int) -> torch.Tensor:
     return ws
 
 
-def groupnorm(a0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, *, a1: Optional[torch.Tensor] = None,
-              silu: bool = False, eps: float = 1e-5) -> torch.Tensor:
-    """GroupNorm (+SiLU) over NHWC (B, H, W, C) / (B, L, C); two sources are normalised as their channel concat."""
+def _groupnorm_call(a0, gamma, beta, groups, a1, silu, eps):
     _gpu(a0, a1, gamma, beta)
     B = a0.shape[0]
     c0 = a0.shape[-1]
     c1 = 0 if a1 is None else a1.shape[-1]
-    hw = a0.numel() // (B * c0) if B else 1
-    stats = torch.empty((B, groups, 2), dtype=torch.float32, device=a0.device)
-    out = torch.empty((*a0.shape[:-1], c0 + c1), dtype=a0.dtype, device=a0.device)
-    lib = _lib.load()
-    code = dt_code(a0.dtype)
-    with torch.cuda.device(a0.device):
-        st = _stream(a0)
-        ws = _gn_workspace(a0.device, B, groups)
-        _lib.check(lib.ldm_groupnorm(a0.data_ptr(), _ptr(a1), c0, c1, code, B, hw, groups, eps, gamma.data_ptr(),
-                                     beta.data_ptr(), 1 if silu else 0, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), st),
-                   "ldm_groupnorm")
-    return out
-
-
-def groupnorm_with_stats(a0, gamma, beta, groups, *, a1=None, silu=False, eps=1e-5):
-    """groupnorm() that also returns the (B, groups, 2) mean/rstd tensor the backward needs."""
-    _gpu(a0, a1, gamma, beta)
-    B = a0.shape[0]
-    c0 = a0.shape[-1]
-    c1 = 0 if a1 is None else a1.shape[-1]
+    _same_dtype_dense("groupnorm", a0, a1)
+    if a1 is not None and a1.shape[:-1] != a0.shape[:-1]:
+        raise ValueError("groupnorm: the two sources must agree in all but the channel dimension")
+    if groups < 1 or (c0 + c1) % groups:
+        raise ValueError(f"groupnorm: {c0 + c1} channels do not divide into {groups} groups")
+    _f32_dense("groupnorm: gamma", gamma, c0 + c1)
+    _f32_dense("groupnorm: beta", beta, c0 + c1)
     hw = a0.numel() // (B * c0) if B else 1
     stats = torch.empty((B, groups, 2), dtype=torch.float32, device=a0.device)
     out = torch.empty((*a0.shape[:-1], c0 + c1), dtype=a0.dtype, device=a0.device)
@@ -463,6 +495,17 @@ def groupnorm_with_stats(a0, gamma, beta, groups, *, a1=None, silu=False, eps=1e
                                      beta.data_ptr(), 1 if silu else 0, out.data_ptr(), stats.data_ptr(), ws.data_ptr(), st),
                    "ldm_groupnorm")
     return out, stats
+
+
+def groupnorm(a0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, *, a1: Optional[torch.Tensor] = None,
+              silu: bool = False, eps: float = 1e-5) -> torch.Tensor:
+    """GroupNorm (+SiLU) over NHWC (B, H, W, C) / (B, L, C); two sources are normalised as their channel concat."""
+    return _groupnorm_call(a0, gamma, beta, groups, a1, silu, eps)[0]
+
+
+def groupnorm_with_stats(a0, gamma, beta, groups, *, a1=None, silu=False, eps=1e-5):
+    """groupnorm() that also returns the (B, groups, 2) mean/rstd tensor the backward needs."""
+    return _groupnorm_call(a0, gamma, beta, groups, a1, silu, eps)
 
 
 _bwd_ws = {}
@@ -487,10 +530,18 @@ def groupnorm_backward(a0, stats, gamma, beta, groups, dy, *, a1=None, silu=Fals
     c0 = a0.shape[-1]
     c1 = 0 if a1 is None else a1.shape[-1]
     hw = a0.numel() // (B * c0) if B else 1
-    if not dy.is_contiguous() or dy.shape[-1] != c0 + c1 or dy.dtype != a0.dtype:
+    _same_dtype_dense("groupnorm_backward", a0, a1)
+    if not dy.is_contiguous() or dy.shape[-1] != c0 + c1 or dy.dtype != a0.dtype or dy.numel() != B * hw * (c0 + c1):
         raise ValueError("groupnorm_backward: dy must be contiguous (.., c0+c1) in the activation dtype")
-    if add is not None and (not add.is_contiguous() or add.shape != dy.shape):
-        raise ValueError("groupnorm_backward: add must be contiguous with dy's shape")
+    if add is not None and (not add.is_contiguous() or add.shape != dy.shape or add.dtype != dy.dtype):
+        raise ValueError("groupnorm_backward: add must be contiguous with dy's shape and dtype")
+    _f32_dense("groupnorm_backward: stats", stats, B * groups * 2)
+    _f32_dense("groupnorm_backward: gamma", gamma, c0 + c1)
+    _f32_dense("groupnorm_backward: beta", beta, c0 + c1)
+    _f32_dense("groupnorm_backward: dgamma", dgamma, c0 + c1)
+    _f32_dense("groupnorm_backward: dbeta", dbeta, c0 + c1)
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("groupnorm_backward: pass both dgamma and dbeta or neither")
     if accumulate is None:
         accumulate = dgamma is not None
     if dgamma is None:
@@ -517,6 +568,14 @@ def layernorm_backward(x, gamma, dy, *, eps: float = 1e-5, add=None, dgamma=None
     _gpu(x, gamma, dy, add, dgamma, dbeta)
     cols = x.shape[-1]
     rows = x.numel() // cols
+    _same_dtype_dense("layernorm_backward", x, dy, add)
+    if dy.shape != x.shape or (add is not None and add.shape != x.shape):
+        raise ValueError("layernorm_backward: dy (and add) must have x's shape")
+    _f32_dense("layernorm_backward: gamma", gamma, cols)
+    _f32_dense("layernorm_backward: dgamma", dgamma, cols)
+    _f32_dense("layernorm_backward: dbeta", dbeta, cols)
+    if (dgamma is None) != (dbeta is None):
+        raise ValueError("layernorm_backward: pass both dgamma and dbeta or neither")
     if accumulate is None:
         accumulate = dgamma is not None
     if dgamma is None:
@@ -541,6 +600,8 @@ def colsum(x: torch.Tensor, segments: int = 1, out: Optional[torch.Tensor] = Non
     rows = x.numel() // n
     if rows % segments:
         raise ValueError("colsum: rows not divisible by segments")
+    if not x.is_contiguous():
+        raise ValueError("colsum: x must be contiguous")
     if accumulate is None:
         accumulate = out is not None
     if out is None:
@@ -560,6 +621,7 @@ def glu_forward(h: torch.Tensor, act: str) -> torch.Tensor:
     """Training form of GEGLU / SwiGLU: h = packed-order pre-activation (.., 2*ff) -> (.., ff)."""
     _gpu(h)
     ff = h.shape[-1] // 2
+    _same_dtype_dense("glu_forward", h)
     out = torch.empty((*h.shape[:-1], ff), dtype=h.dtype, device=h.device)
     with torch.cuda.device(h.device):
         _lib.check(_lib.load().ldm_glu_forward(h.data_ptr(), out.data_ptr(), dt_code(h.dtype), h.numel() // (2 * ff), ff,
@@ -570,6 +632,9 @@ def glu_forward(h: torch.Tensor, act: str) -> torch.Tensor:
 def glu_backward(h: torch.Tensor, dout: torch.Tensor, act: str) -> torch.Tensor:
     _gpu(h, dout)
     ff = h.shape[-1] // 2
+    _same_dtype_dense("glu_backward", h, dout)
+    if dout.numel() * 2 != h.numel():
+        raise ValueError("glu_backward: dout must have half of h's columns")
     dh = torch.empty_like(h)
     with torch.cuda.device(h.device):
         _lib.check(_lib.load().ldm_glu_backward(h.data_ptr(), dout.data_ptr(), dh.data_ptr(), dt_code(h.dtype),
@@ -609,6 +674,9 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 def silu_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     _gpu(x, dy)
+    _same_dtype_dense("silu_backward", x, dy)
+    if dy.numel() != x.numel():
+        raise ValueError("silu_backward: dy must have x's element count")
     dx = torch.empty_like(x)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_silu_backward(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), dt_code(x.dtype), x.numel(),
@@ -619,6 +687,9 @@ def silu_backward(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     _gpu(x, gamma, beta)
     cols = x.shape[-1]
+    _same_dtype_dense("layernorm", x)
+    _f32_dense("layernorm: gamma", gamma, cols)
+    _f32_dense("layernorm: beta", beta, cols)
     out = torch.empty_like(x)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_layernorm(x.data_ptr(), dt_code(x.dtype), x.numel() // cols, cols, eps, gamma.data_ptr(),
@@ -635,6 +706,8 @@ def attention(q: torch.Tensor, kv: torch.Tensor, heads: int) -> torch.Tensor:
     if kv.shape[2] != 2 * Cq or Cq % heads:
         raise ValueError("attention: kv must have 2*C columns and C must divide into heads")
     d = Cq // heads
+    _rows3("attention: q", q, q.dtype, B, Lq, Cq)
+    _rows3("attention: kv", kv, q.dtype, B, Lk, 2 * Cq)
     out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     es = q.element_size()
     with torch.cuda.device(q.device):
@@ -652,6 +725,8 @@ def attention_train(q: torch.Tensor, kv: torch.Tensor, heads: int):
     if kv.shape[2] != 2 * Cq or Cq % heads:
         raise ValueError("attention: kv must have 2*C columns and C must divide into heads")
     d = Cq // heads
+    _rows3("attention: q", q, q.dtype, B, Lq, Cq)
+    _rows3("attention: kv", kv, q.dtype, B, Lk, 2 * Cq)
     out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
     lse = torch.empty((B, heads, Lq), dtype=torch.float32, device=q.device)
     es = q.element_size()
@@ -673,9 +748,12 @@ def attention_backward(q, kv, out, dout, lse, heads, dq=None, dkv=None):
         dq = torch.empty((B, Lq, Cq), dtype=q.dtype, device=q.device)
     if dkv is None:
         dkv = torch.empty((B, Lk, 2 * Cq), dtype=q.dtype, device=q.device)
-    for t in (q, kv, out, dout, dq, dkv):
-        if t.stride(-1) != 1 or t.stride(0) != t.shape[1] * t.stride(1):
-            raise ValueError("attention_backward: operands must be row-strided (B, L, C) views with unit column stride")
+    if kv.dim() != 3 or kv.shape[2] != 2 * Cq or Cq % heads:
+        raise ValueError("attention_backward: kv must have 2*C columns and C must divide into heads")
+    for nm, t, rows, cols in (("q", q, Lq, Cq), ("kv", kv, Lk, 2 * Cq), ("out", out, Lq, Cq), ("dout", dout, Lq, Cq),
+                              ("dq", dq, Lq, Cq), ("dkv", dkv, Lk, 2 * Cq)):
+        _rows3("attention_backward: " + nm, t, q.dtype, B, rows, cols)
+    _f32_dense("attention_backward: lse", lse, B * heads * Lq)
     delta = torch.empty((B, heads, Lq), dtype=torch.float32, device=q.device)
     es = q.element_size()
     with torch.cuda.device(q.device):
@@ -703,6 +781,8 @@ def conv_in(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype: tor
     x = x.contiguous()
     B, cin, H, W = x.shape
     cout = w.shape[0]
+    _f32_dense("conv_in: filter", w, cout * cin * 9)
+    _f32_dense("conv_in: bias", bias, cout)
     out = torch.empty((B, H, W, cout), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_conv_in(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
@@ -715,6 +795,9 @@ def conv_out(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, out_dtype: to
     _gpu(x, w, bias)
     B, H, W, cin = x.shape
     cout = w.shape[0]
+    _same_dtype_dense("conv_out", x)
+    _f32_dense("conv_out: filter", w, cout * cin * 9)
+    _f32_dense("conv_out: bias", bias, cout)
     out = torch.empty((B, cout, H, W), dtype=out_dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_conv_out(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),
@@ -751,8 +834,8 @@ def conv1x1_nchw(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.
     x = x.contiguous()
     B, cin, H, W = x.shape
     cout = w.shape[0]
-    if w.numel() != cout * cin:
-        raise ValueError("conv1x1_nchw: filter does not match the input channels")
+    _f32_dense("conv1x1_nchw: filter", w, cout * cin)
+    _f32_dense("conv1x1_nchw: bias", bias, cout)
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().ldm_conv1x1_nchw(x.data_ptr(), dt_code(x.dtype), w.data_ptr(), bias.data_ptr(), out.data_ptr(),

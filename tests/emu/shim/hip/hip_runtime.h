@@ -195,8 +195,16 @@ static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int)
   return r;
 }
 
+// stores past the record count are dropped by the range check (same rule as the loads); the cache-policy bits do nothing here
+static inline void raw_buffer_store_b128(u32x4_emu v, rsrc_t rs, int voff, int soff, int) {
+  const unsigned long long chk = (unsigned long long)(unsigned)voff + (soff_checked() ? (unsigned)soff : 0u);
+  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  if (chk + 16 <= rs.bytes) memcpy(const_cast<unsigned char*>(rs.base) + off, &v, 16);
+}
+
 }  // namespace emu
 
+#define __builtin_amdgcn_raw_buffer_store_b128 ::emu::raw_buffer_store_b128
 #define __amdgpu_buffer_rsrc_t ::emu::rsrc_t
 #define __builtin_amdgcn_make_buffer_rsrc ::emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds ::emu::raw_ptr_buffer_load_lds
@@ -241,6 +249,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 template <typename T>
 static inline hipError_t hipGetSymbolAddress(void** p, T& sym) { *p = (void*)&sym; return hipSuccess; }

@@ -3,7 +3,7 @@ vectors taken from the reference.
 
 Tolerance: BIT-EXACT against the oracle evaluated on the same host (float32 IEEE operations in the reference's
 order).  Against the golden files (generated in the build container) the tables that go through torch's CPU
-sqrt are allowed 1 ulp (4 ulp where a product and a quotient follow the square root) in at most 400 of 1000 entries and what is computed from them 1e-6 relative L2: torch's CPU sqrt is MKL's, which is not correctly
+sqrt are allowed 1 ulp (4 ulp where a product and a quotient follow the square root) in at most 320 of 1000 entries (measured on the boxes of the pool: 6 ... 285; the counts of the last run are kept in profiles/) and what is computed from them 1e-6 relative L2: torch's CPU sqrt is MKL's, which is not correctly
 rounded and differs between host CPUs (measured: 6/1000 entries of sqrt_alphas_cumprod differ by 1 ulp between
 the build container and the GPU box), so the reference itself is only reproducible to that level across hosts.
 betas, alphas_cumprod and the timestep lists are bit-exact against the golden files everywhere."""
@@ -39,7 +39,7 @@ def test_tables_on_device_bit_exact(golden, sched):
             print(f"{k}: {ndiff}/1000 entries differ from the build container's by 1 ulp")
             # a table that IS a square root: 1 ulp; posterior_mean_coef1/2 multiply and divide a 1-ulp-off square root: 4
             assert max_ulp(dev, ref) <= (4 if k.startswith("posterior_mean") else 1), k
-            assert ndiff <= 400, (k, ndiff)
+            assert ndiff <= 320, (k, ndiff)      # measured over the pool's hosts: 6 ... 285
 
 
 @pytest.mark.parametrize("schedule", ["linear", "cosine"])

@@ -12,13 +12,13 @@ ROOT=$PWD
 mkdir -p "$OUT/trace" "$OUT/pmc"
 export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- \
-  python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --plain-only > "$OUT/trace.log" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-  -d "$OUT/pmc" -o sq --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc/sq.log" 2>&1
+  -d "$OUT/pmc" -o sq --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --plain-only > "$OUT/pmc/sq.log" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc" -o fetch --output-format csv -- \
-  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc/fetch.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --plain-only > "$OUT/pmc/fetch.log" 2>&1
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc" -o write --output-format csv -- \
-  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc/write.log" 2>&1
+  python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --plain-only > "$OUT/pmc/write.log" 2>&1
 python3 tools/kernel_stats_summary.py "$OUT/trace" 7 > "$OUT/${TAG}_bench_summary.md"
 python3 tools/pmc_summary.py "$OUT/pmc" 3 --json bench_pmc_traffic.json --workload fwd_b32_l64 --profile "profiles/${TAG}_pmc_per_kernel.md" \
   > "$OUT/${TAG}_pmc_per_kernel.md"

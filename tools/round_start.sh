@@ -1,22 +1,35 @@
 #!/bin/bash
-# First GPU call of a round: everything round 2 could not measure after gpurun closed (DESIGN.md sections 8.0 and 9), in one
-# call, every step under its own time limit, stopping at the first failure.  Run on the GPU box from the repo root:
+# First GPU call of a round: the whole -m gpu suite, the headline bench (its line carries the LayerNorm-fold A/B and the
+# HBM-kernel rows), same-box A/B legs of the switches under study, the side benches, then the rocprofv3 evidence
+# (tools/profile_bench.sh: kernel trace + three PMC passes, bench_pmc_traffic.json).  Every GPU step has its own time limit;
+# the script stops at the first step that ends in anything but success (a failed ASSERTION in the test suite -- pytest exit
+# status 1 -- is reported and the run goes on; an abort, a fault or a time limit ends it).  On the GPU box, from the repo root:
 #   gpurun --timeout 1200 -- 'bash tools/round_start.sh gpurun_out/r3_start'
-# Leaves under $OUT: gpu_tests.log, bench.json.log (with the fold A/B and the HBM-kernel rows inside the line), bench_nofold,
-# attention / norm / train bench tables, the soffset hardware probe, and the rocprofv3 kernel trace + PMC summaries.
-set -e -o pipefail
+set -o pipefail
 OUT=${1:-gpurun_out/round_start}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-hipcc --offload-arch=gfx950 -O2 tools/probes/soffset_range_check.hip -o /tmp/soff_probe > "$OUT/probe_build.log" 2>&1
-timeout -k 10 60 /tmp/soff_probe | tee "$OUT/soffset_probe.txt"
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > "$OUT/gpu_tests.log" 2>&1 || { tail -30 "$OUT/gpu_tests.log"; exit 1; }
-tail -3 "$OUT/gpu_tests.log"
-timeout -k 10 300 python -u bench.py > "$OUT/bench.json.log" 2>&1 || { tail -20 "$OUT/bench.json.log"; exit 1; }
-grep -h '"metric"' "$OUT/bench.json.log" | cut -c1-600
-LDM_ATTN_V1=1 LDM_BENCH_AB=0 timeout -k 10 300 python -u bench.py --no-cpu-baseline > "$OUT/bench_attn_v1.json.log" 2>&1
-timeout -k 10 300 python -u tools/attention_bench.py > "$OUT/attention_bench.txt" 2>&1
-timeout -k 10 300 python -u tools/norm_bench.py > "$OUT/norm_bench.txt" 2>&1
-timeout -k 10 600 python -u bench.py --train > "$OUT/bench_train.json.log" 2>&1
-timeout -k 10 600 python -u bench.py --strong > "$OUT/bench_strong.json.log" 2>&1
+step() {  # step <seconds> <logfile> <command...>
+  local lim=$1 log=$2; shift 2
+  timeout -k 10 "$lim" "$@" > "$log" 2>&1
+  local rc=$?
+  echo "[$(date +%H:%M:%S)] rc=$rc  $*  -> $log"
+  return $rc
+}
+step 900 "$OUT/gpu_tests.log" python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -x
+rc=$?
+tail -4 "$OUT/gpu_tests.log"
+if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "test run ended with status $rc: stopping"; exit $rc; fi
+step 300 "$OUT/bench.json.log" python -u bench.py || { tail -20 "$OUT/bench.json.log"; exit 1; }
+grep -h '"metric"' "$OUT/bench.json.log" | cut -c1-700
+LDM_BENCH_AB=0 LDM_WT_STORES=1 step 200 "$OUT/bench_wt.json.log" python -u bench.py --no-cpu-baseline || exit 1
+LDM_BENCH_AB=0 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_mb2.json.log" python -u bench.py --no-cpu-baseline || exit 1
+LDM_BENCH_AB=0 LDM_WT_STORES=1 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_wt_mb2.json.log" python -u bench.py --no-cpu-baseline || exit 1
+LDM_BENCH_AB=0 step 200 "$OUT/bench_again.json.log" python -u bench.py --no-cpu-baseline || exit 1
+for f in bench_wt bench_mb2 bench_wt_mb2 bench_again; do echo "$f: $(grep -h '"metric"' "$OUT/$f.json.log" | cut -c1-260)"; done
+step 300 "$OUT/attention_bench.txt" python -u tools/attention_bench.py || exit 1
+step 300 "$OUT/norm_bench.txt" python -u tools/norm_bench.py || exit 1
+step 600 "$OUT/bench_train.json.log" python -u bench.py --train || exit 1
+LDM_WT_STORES=1 step 600 "$OUT/bench_train_wt.json.log" python -u bench.py --train || exit 1
+step 600 "$OUT/bench_strong.json.log" python -u bench.py --strong || exit 1
 bash tools/profile_bench.sh "$OUT/prof" r3
