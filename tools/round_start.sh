@@ -7,6 +7,7 @@
 #   gpurun --timeout 1200 -- 'bash tools/round_start.sh gpurun_out/r3_start'
 set -o pipefail
 OUT=${1:-gpurun_out/round_start}
+STAGE=${2:-all}     # "a": tests + headline bench + A/B legs; "b": side benches + rocprofv3; "all": both (about 20 minutes)
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 step() {  # step <seconds> <logfile> <command...>
@@ -16,6 +17,7 @@ step() {  # step <seconds> <logfile> <command...>
   echo "[$(date +%H:%M:%S)] rc=$rc  $*  -> $log"
   return $rc
 }
+if [ "$STAGE" != b ]; then
 step 900 "$OUT/gpu_tests.log" python -u -m pytest tests -m gpu -q --timeout 300 --timeout-method thread -x
 rc=$?
 tail -4 "$OUT/gpu_tests.log"
@@ -27,6 +29,8 @@ LDM_BENCH_AB=0 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_mb2.json.log" pyth
 LDM_BENCH_AB=0 LDM_WT_STORES=1 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_wt_mb2.json.log" python -u bench.py --no-cpu-baseline || exit 1
 LDM_BENCH_AB=0 step 200 "$OUT/bench_again.json.log" python -u bench.py --no-cpu-baseline || exit 1
 for f in bench_wt bench_mb2 bench_wt_mb2 bench_again; do echo "$f: $(grep -h '"metric"' "$OUT/$f.json.log" | cut -c1-260)"; done
+fi
+if [ "$STAGE" = a ]; then exit 0; fi
 step 300 "$OUT/attention_bench.txt" python -u tools/attention_bench.py || exit 1
 step 300 "$OUT/norm_bench.txt" python -u tools/norm_bench.py || exit 1
 step 600 "$OUT/bench_train.json.log" python -u bench.py --train || exit 1
