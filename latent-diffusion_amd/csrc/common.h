@@ -94,28 +94,6 @@ __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 
-// Write-through forms of store8 (`buffer_store_dwordx4 ... sc1`): the bytes leave the XCD's L2 as they are stored instead of
-// sitting there dirty until the end-of-kernel release writes the whole L2 back (MI355X_MICROARCH.md, price list row
-// "boundary": + dirty bytes / 6 TB/s on every dependent kernel boundary -- up to ~5 us behind a kernel that leaves 32 MB
-// dirty).  `base` / `bytes` must be wave-uniform (the tensor, < 4 GiB); `off` is the lane's byte offset inside it.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_st_t;
-__device__ __forceinline__ void store16_wt(void* base, unsigned bytes, unsigned off, u32x4_st_t v) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(v, rs, (int)off, 0, 16);   // aux 16 = sc1
-}
-__device__ __forceinline__ void store8_wt(bf16_t* base, unsigned bytes, size_t elem, const float (&v)[8]) {
-  const u32x4_st_t r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-  store16_wt(base, bytes, (unsigned)(elem * 2), r);
-}
-__device__ __forceinline__ void store8_wt(float* base, unsigned bytes, size_t elem, const float (&v)[8]) {
-  const u32x4_st_t lo = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-  const u32x4_st_t hi = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
-  store16_wt(base, bytes, (unsigned)(elem * 4), lo);
-  store16_wt(base, bytes, (unsigned)(elem * 4 + 16), hi);
-}
-// LDM_WT_STORES=0 keeps plain stores everywhere (A/B runs); read once per process.
-bool wt_stores_enabled();
-
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

@@ -41,12 +41,12 @@ struct ConvGemmParams {
   int ln_nseg;
   const float* ln_s1;     //   [N]: sum_k W'[n][k] of the gamma-scaled filter this call multiplies with
   float ln_eps;
-  int wt;           // write-through (sc1) stores for the output / the split-K partial sums (common.h store8_wt)
-  unsigned out_bytes;
   int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
   float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
   unsigned long long* stamps;  // diagnostic build only (make stamps): 16 cycle stamps per workgroup
+  int ablate;                  // diagnostic build only (LDM_GEMM_ABLATE): 1 = no LDS-DMA in the ring loop, 2 = no MFMA (fragment
+                               // reads kept), 4 = neither fragment reads nor MFMA -- results are garbage, only the timing is read
 #endif
 };
 
@@ -60,6 +60,11 @@ struct ConvGemmParams {
   } while (0)
 #else
 #define LDM_STAMP(i) do {} while (0)
+#endif
+#ifdef LDM_GEMM_STAMPS
+#define LDM_ABLATE(bit) (p.ablate & (bit))
+#else
+#define LDM_ABLATE(bit) false
 #endif
 
 template <int CH>
@@ -125,22 +130,29 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   // ---- LDM_EPI_LNFOLD: mean / rstd of this workgroup's rows of A from the producer's per-segment partial sums (fixed
-  // order: deterministic); thread r owns row m0 + r and keeps the pair in two registers until the epilogue.  Loaded and
-  // consumed here, before any LDS-DMA is in flight (a later use of an ordinary load would drain the DMA queue).
-  float ln_mu = 0.f, ln_r = 0.f;
-  if (p.ln_stats != nullptr && tid < BM && m0 + tid < p.M) {
+  // order: deterministic); thread r owns row m0 + r.  The loads are ISSUED here, ahead of the first LDS-DMA, and folded
+  // only after the prologue's DMA has been issued (ln_finish below): consumed at once, their memory latency came in front of
+  // the tile's first operand fetch -- a tenth of the life of a K = 320 tile (GLU launches: +27 us with the fold on).
+  constexpr int LN_MAX_SEG = 16;             // 80-column segments of a row: c0 <= 1280 (checked on the host)
+  float2 ln_raw[LN_MAX_SEG];
+  const bool ln_row = p.ln_stats != nullptr && tid < BM && m0 + tid < p.M;
+  if (ln_row) {
     const float2* st = reinterpret_cast<const float2*>(p.ln_stats) + (size_t)(m0 + tid) * p.ln_nseg;
-    float sx = 0.f, sq = 0.f;
-    for (int i = 0; i < p.ln_nseg; ++i) {
-      const float2 v = st[i];
-      sx += v.x;
-      sq += v.y;
-    }
-    const float inv_k = 1.0f / (float)p.K;
-    ln_mu = sx * inv_k;
-    const float var = fmaxf(sq * inv_k - ln_mu * ln_mu, 0.f);
-    ln_r = rsqrtf(var + p.ln_eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_SEG; ++i) ln_raw[i] = i < p.ln_nseg ? st[i] : make_float2(0.f, 0.f);
   }
+  float ln_mu = 0.f, ln_r = 0.f;
+  auto ln_finish = [&]() {
+    if (ln_row) {
+      float sx = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAX_SEG; ++i) { sx += ln_raw[i].x; sq += ln_raw[i].y; }
+      const float inv_k = 1.0f / (float)p.K;
+      ln_mu = sx * inv_k;
+      const float var = fmaxf(sq * inv_k - ln_mu * ln_mu, 0.f);
+      ln_r = rsqrtf(var + p.ln_eps);
+    }
+  };
 
   // ---- operand staging: LDS-DMA through buffer descriptors.  Per K-tile a wave issues A_IT + B_IT
   // `buffer_load_dwordx4 ... offen lds` with a per-lane byte offset that stays fixed while the K loop walks the
@@ -279,6 +291,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       ([&] {
         constexpr int ks = KSI;
         bf16x8_t af[MI], bfr[NI];
+        if (!LDM_ABLATE(4)) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           const int row = wm * WTM + i * 16 + fr;
@@ -289,13 +302,22 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           const int row = wn * WTN + j * 16 + fr;
           bfr[j] = *reinterpret_cast<const bf16x8_t*>(sb + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
         }
+        }
+#ifdef LDM_GEMM_STAMPS
+        if (LDM_ABLATE(2)) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(af[i]));
+#pragma unroll
+          for (int j = 0; j < NI; ++j) asm volatile("" ::"v"(bfr[j]));
+        }
+#endif
         [&]<int... IJ>(std::integer_sequence<int, IJ...>) {
           ([&] {
             constexpr int i = IJ / NI, j = IJ % NI;
             constexpr int seq = ks * MI * NI + IJ;           // MFMA number inside the K-tile
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (!LDM_ABLATE(6)) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             if constexpr ((seq + 1) % GAP == 0 && (seq + 1) / GAP - 1 < NPIECE) {
-              if (do_stage) {
+              if (do_stage && !LDM_ABLATE(1)) {
                 __builtin_amdgcn_sched_barrier(0);
                 stage_piece(std::integral_constant<int, (seq + 1) / GAP - 1>{});
                 __builtin_amdgcn_sched_barrier(0);
@@ -334,6 +356,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   LDM_STAMP(1);
   if constexpr (STAGES == 2) {
     stage(0, kt_begin);
+    ln_finish();
     __syncthreads();  // waits vmcnt(0) for the LDS-DMA, then barrier
     LDM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
@@ -356,6 +379,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     const bool extra = B_IT > B_FULL && (B_FULL * NT + wave * 64) < BN * CH;
     stage(0, kt_begin);
     if (nk > 1) stage(1, kt_begin + 1);
+    ln_finish();
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) {
@@ -381,15 +405,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
   LDM_STAMP(3);
   // ---- LDM_EPI_LNFOLD: row statistics and the column sums of the scaled filter go to LDS behind the epilogue's staging area
   constexpr int EPI_CST_BYTES = WM * WN * 16 * (WTN + 4) * 4;
-  constexpr int EPI_LN_BYTES = BM * 8 + BN * 4;
+  constexpr int EPI_LN_BYTES = BM * 8;
   constexpr int EPI_RST_BYTES = WM * WN * 16 * (WTN / 8) * 8;
   static_assert(EPI_CST_BYTES + EPI_LN_BYTES + EPI_RST_BYTES <= STAGES * STAGE, "epilogue scratch does not fit the tile buffers");
-  float* const lnst = reinterpret_cast<float*>(smem + EPI_CST_BYTES);     // [BM][2] mean, rstd
-  float* const lns1 = lnst + BM * 2;                                       // [BN]
+  float* const lnst = reinterpret_cast<float*>(smem + EPI_CST_BYTES);     // [BM][2]: rstd, -mean * rstd
   const bool has_ln = p.ln_stats != nullptr;
   if (has_ln) {
-    if (tid < BM) { lnst[2 * tid] = ln_mu; lnst[2 * tid + 1] = ln_r; }
-    for (int c = tid; c < BN; c += NT) lns1[c] = n0 + c < p.N ? p.ln_s1[n0 + c] : 0.f;
+    if (tid < BM) { lnst[2 * tid] = ln_r; lnst[2 * tid + 1] = -ln_mu * ln_r; }
     __syncthreads();
   }
   // ---- epilogue: C[row = fq*4 + r][col = fr] per 16x16 tile
@@ -436,6 +458,20 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         if (cok[ps] && (epi & LDM_EPI_BIAS)) {
           load8(p.bias + ncol[ps], bv[ps]);
           if (GLU) load8(p.bias + ncol[ps] + 16, bg[ps]);
+        }
+      }
+      // LDM_EPI_LNFOLD: y = rstd * acc + (-mean * rstd) * colsum(W')[n] + bias'[n].  colsum lives in registers like the bias (one
+      // load per lane before the loop); the two per-row factors come from LDS once per 16-row step.
+      float s1v[NPASS][8], s1g[GLU ? NPASS : 1][8];
+      if (has_ln) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s1v[ps][e] = 0.f; if (GLU) s1g[ps][e] = 0.f; }
+          if (cok[ps]) {
+            load8(p.ln_s1 + ncol[ps], s1v[ps]);
+            if (GLU) load8(p.ln_s1 + ncol[ps] + 16, s1g[ps]);
+          }
         }
       }
       const bool has_res = !GLU && (epi & LDM_EPI_RESIDUAL), has_row = !GLU && (epi & LDM_EPI_ROWVEC);
@@ -485,31 +521,33 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           const float4 x0 = *reinterpret_cast<const float4*>(src);
           const float4 x1 = *reinterpret_cast<const float4*>(src + 4);
           v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-          float mu = 0.f, rr = 1.f;
+          float rr = 1.f, nm = 0.f;
           if (has_ln) {   // y = rstd * (x W'^T - mean * colsum(W')) + (bias + W beta): LayerNorm folded into this GEMM
             const float2 st = *reinterpret_cast<const float2*>(lnst + 2 * (wm * WTM + i * 16 + row[ps]));
-            mu = st.x; rr = st.y;
-            const float* s1p = lns1 + wn * WTN + scol[ps];
+            rr = st.x; nm = st.y;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = rr * (v[e] - mu * s1p[e]);
+            for (int e = 0; e < 8; ++e) v[e] = fmaf(rr, v[e], fmaf(nm, s1v[ps][e], bv[ps][e]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bv[ps][e];
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += bv[ps][e];
           if constexpr (GLU) {
             const float4 g0 = *reinterpret_cast<const float4*>(src + 16);
             const float4 g1 = *reinterpret_cast<const float4*>(src + 20);
             float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             if (has_ln) {
-              const float* s1g = lns1 + wn * WTN + scol[ps] + 16;
 #pragma unroll
-              for (int e = 0; e < 8; ++e) g[e] = rr * (g[e] - mu * s1g[e]);
+              for (int e = 0; e < 8; ++e) g[e] = fmaf(rr, g[e], fmaf(nm, s1g[ps][e], bg[ps][e]));
+            } else {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) g[e] += bg[ps][e];
             }
             if (epi & LDM_EPI_GEGLU) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_fast(g[e] + bg[ps][e]);
+              for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_fast(g[e]);
             } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] *= silu_fast(g[e] + bg[ps][e]);
+              for (int e = 0; e < 8; ++e) v[e] *= silu_fast(g[e]);
             }
           } else {
             if (has_row) add_bf16x8(v, rrow[ps]);
@@ -519,13 +557,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             }
             if (has_res) add_bf16x8(v, rres[ps]);
           }
-          if (p.wt) {
-            if (out_f32) store8_wt(static_cast<float*>(outp), p.out_bytes, (size_t)m * nout + ocol[ps], v);
-            else store8_wt(static_cast<bf16_t*>(outp), p.out_bytes, (size_t)m * nout + ocol[ps], v);
-          } else {
-            if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
-            else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
-          }
+          if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
+          else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
           if (want_stats) {
             float sx = 0.f, sq = 0.f;
 #pragma unroll
@@ -650,13 +683,8 @@ splitk_reduce_kernel(const ConvGemmParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += t[e];
   }
-  if (p.wt) {
-    if (p.out_f32) store8_wt(static_cast<float*>(p.out), p.out_bytes, (size_t)m * p.N + n, v);
-    else store8_wt(static_cast<bf16_t*>(p.out), p.out_bytes, (size_t)m * p.N + n, v);
-  } else {
-    if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * p.N + n, v);
-    else store8(static_cast<bf16_t*>(p.out) + (size_t)m * p.N + n, v);
-  }
+  if (p.out_f32) store8(static_cast<float*>(p.out) + (size_t)m * p.N + n, v);
+  else store8(static_cast<bf16_t*>(p.out) + (size_t)m * p.N + n, v);
 }
 
 // ------------------------------------------------------------------------------------------- fp32
@@ -825,9 +853,6 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(p.tiles_m * p.tiles_n, p.splits), dim3(64 * WM * WN), smem, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(bf16)");
   if (p.splits > 1) {
-    const long long fb = (long long)p.M * p.N * (p.out_f32 ? 4 : 2);
-    p.wt = p.wt && fb < (1LL << 32) ? 1 : 0;
-    p.out_bytes = (unsigned)fb;
     const long long chunks = (long long)p.M * (p.N / 8);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, p);
     LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(split-K fold)");
@@ -945,8 +970,6 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.residual = d->residual; p.out = d->out;
   p.out_f32 = d->out_dtype == LDM_F32;
   p.vec_epilogue = 0;
-  p.wt = 0;
-  p.out_bytes = 0;
   p.splits = 1;
   p.partial = nullptr;
   p.rowstats = (epi & LDM_EPI_ROWSTATS) ? d->rowstats : nullptr;
@@ -956,6 +979,10 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.ln_eps = d->ln_eps;
 #ifdef LDM_GEMM_STAMPS
   p.stamps = nullptr;
+  {
+    static const int abl = [] { const char* e = getenv("LDM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    p.ablate = abl;
+  }
 #endif
   hipStream_t st = (hipStream_t)stream;
   if (epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD)) {
@@ -964,7 +991,7 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
       LDM_REQUIRE(d->rowstats && !glu && d->n % 160 == 0 && (reinterpret_cast<uintptr_t>(d->rowstats) & 7) == 0,
                   "ldm_conv_gemm: LDM_EPI_ROWSTATS needs a rowstats buffer, no GLU and n %% 160 == 0 (n=%d)", d->n);
     if (epi & LDM_EPI_LNFOLD)
-      LDM_REQUIRE(d->ln_stats && d->ln_colsum && d->ln_segments >= 1 && d->ln_segments <= 64 && d->ksize == 1 && d->c1 == 0 &&
+      LDM_REQUIRE(d->ln_stats && d->ln_colsum && d->ln_segments >= 1 && d->ln_segments <= 16 && d->ksize == 1 && d->c1 == 0 &&
                       d->stride == 1 && !d->upsample && d->ln_eps > 0.f && (reinterpret_cast<uintptr_t>(d->ln_stats) & 7) == 0,
                   "ldm_conv_gemm: LDM_EPI_LNFOLD needs ln_stats / ln_colsum / ln_segments and a plain (1x1, single-source) layer");
     // the statistics are per 80-column segment of the tensor this call reads as A: any other count would read past the
@@ -1009,14 +1036,6 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
                      !(epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD));       // the split-K fold kernel knows neither
   pick_tile_bf16(p, glu, ws_ok ? d->workspace_bytes : 0, bm, bn, bk, p.splits);
   p.partial = static_cast<float*>(d->workspace);
-  {
-    // write-through stores address the output through a 32-bit buffer descriptor: the tensor (one split's partial sums) must
-    // stay under 4 GiB; the split-K fold kernel writes the real output, whose size is set before its launch
-    const int nout = glu ? p.N / 2 : p.N;
-    const long long ob = p.splits > 1 ? (long long)p.M * p.N * 4 : (long long)p.M * nout * (p.out_f32 ? 4 : 2);
-    p.wt = wt_stores_enabled() && p.vec_epilogue && ob < (1LL << 32) ? 1 : 0;
-    p.out_bytes = (unsigned)ob;
-  }
   // row statistics are laid out per 80-column wave tile of a BN = 160 tile (rowstats[m][n / 80][2]): any other tile would
   // write a different segment count than the caller allocated
   LDM_REQUIRE(!(epi & LDM_EPI_ROWSTATS) || (bn == 160 && bk == 64),

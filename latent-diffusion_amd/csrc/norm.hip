@@ -274,7 +274,20 @@ gn_fused_kernel(const bf16_t* __restrict__ a0, const bf16_t* __restrict__ a1, Gn
   float* red = reinterpret_cast<float*>(smem_raw);          // [pix][seg][2]
   __shared__ float gstat[4][2];
   __shared__ double gpart[4][16][2];
-  const int b = blockIdx.y, set = blockIdx.x;
+  // (sample, group set) of this workgroup.  The group sets of one sample read and write DIFFERENT 16..80-byte pieces of the
+  // SAME 128-byte lines (a pixel's channels are contiguous), and workgroups are dealt round-robin over the 8 XCDs, each with
+  // its own L2: in launch order the 8 group sets of a sample sat on 8 different XCDs, every one of which fetched the whole
+  // line and wrote its piece back separately (rocprofv3, 32 x 64 x 64 x 320: 230 MB fetched and 114 MB written per launch for
+  // 84 + 84 MB of data).  Give every XCD a contiguous run of (sample, set) pairs instead (blocks l and l + 8 share an XCD):
+  // a sample's sets then run at the same time on ONE XCD, whose L2 fetches each line once and merges the partial writes.
+  int b, set;
+  {
+    const int nblk = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, x = lin & 7;
+    const int t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (lin >> 3);
+    b = t / (int)gridDim.x;
+    set = t - b * (int)gridDim.x;
+  }
   const int seg = g.gs * g.cpg;                              // channels of this workgroup
   const int cbase = set * seg;
   const int tid = threadIdx.x;

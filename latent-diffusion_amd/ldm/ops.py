@@ -239,7 +239,7 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
 def ln_fold_supported(channels: int, dtype: torch.dtype) -> bool:
     """The LayerNorm fold needs bf16 and a producer whose rows are whole 80-column wave tiles of BN = 160, BK = 64 GEMM
     tiles: channel counts in multiples of lcm(160, 64) = 320 (320 / 640 / 1280 in the SD-1.5-shaped model)."""
-    return dtype == torch.bfloat16 and channels % 320 == 0
+    return dtype == torch.bfloat16 and channels % 320 == 0 and channels <= 1280   # <= 16 statistics segments per row
 
 
 def fold_layernorm_terms(w: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype):

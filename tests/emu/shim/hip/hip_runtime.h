@@ -195,16 +195,8 @@ static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int)
   return r;
 }
 
-// stores past the record count are dropped by the range check (same rule as the loads); the cache-policy bits do nothing here
-static inline void raw_buffer_store_b128(u32x4_emu v, rsrc_t rs, int voff, int soff, int) {
-  const unsigned long long chk = (unsigned long long)(unsigned)voff + (soff_checked() ? (unsigned)soff : 0u);
-  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
-  if (chk + 16 <= rs.bytes) memcpy(const_cast<unsigned char*>(rs.base) + off, &v, 16);
-}
-
 }  // namespace emu
 
-#define __builtin_amdgcn_raw_buffer_store_b128 ::emu::raw_buffer_store_b128
 #define __amdgpu_buffer_rsrc_t ::emu::rsrc_t
 #define __builtin_amdgcn_make_buffer_rsrc ::emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds ::emu::raw_ptr_buffer_load_lds
@@ -222,6 +214,7 @@ static inline void raw_buffer_store_b128(u32x4_emu v, rsrc_t rs, int voff, int s
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_memtime ::emu::clock_ticks
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_s_memrealtime ::emu::clock_ticks
 #define __builtin_amdgcn_exp2f(x) exp2f(x)
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))

@@ -27,6 +27,10 @@ CASES = [  # name, (H, W, C0, C1), N, ksize, stride, up, glu
     ("L1 geglu 640->5120", (32, 32, 640, 0), 5120, 1, 1, False, "geglu"),
     ("L2 geglu 1280->10240", (16, 16, 1280, 0), 10240, 1, 1, False, "geglu"),
     ("ctx kv 768->640", (77, 1, 768, 0), 640, 1, 1, False, None),
+    # the GLU projections' shapes WITHOUT the gate epilogue: what the tile alone is worth on them
+    ("L0 ff1 plain 320->2560", (64, 64, 320, 0), 2560, 1, 1, False, None),
+    ("L1 ff1 plain 640->5120", (32, 32, 640, 0), 5120, 1, 1, False, None),
+    ("L2 ff1 plain 1280->10240", (16, 16, 1280, 0), 10240, 1, 1, False, None),
 ]
 
 

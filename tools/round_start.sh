@@ -24,16 +24,13 @@ tail -4 "$OUT/gpu_tests.log"
 if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "test run ended with status $rc: stopping"; exit $rc; fi
 step 300 "$OUT/bench.json.log" python -u bench.py || { tail -20 "$OUT/bench.json.log"; exit 1; }
 grep -h '"metric"' "$OUT/bench.json.log" | cut -c1-700
-LDM_BENCH_AB=0 LDM_WT_STORES=1 step 200 "$OUT/bench_wt.json.log" python -u bench.py --no-cpu-baseline || exit 1
 LDM_BENCH_AB=0 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_mb2.json.log" python -u bench.py --no-cpu-baseline || exit 1
-LDM_BENCH_AB=0 LDM_WT_STORES=1 LDM_MICRO_BATCH_STREAMS=2 step 200 "$OUT/bench_wt_mb2.json.log" python -u bench.py --no-cpu-baseline || exit 1
 LDM_BENCH_AB=0 step 200 "$OUT/bench_again.json.log" python -u bench.py --no-cpu-baseline || exit 1
-for f in bench_wt bench_mb2 bench_wt_mb2 bench_again; do echo "$f: $(grep -h '"metric"' "$OUT/$f.json.log" | cut -c1-260)"; done
+for f in bench_mb2 bench_again; do echo "$f: $(grep -h '"metric"' "$OUT/$f.json.log" | cut -c1-260)"; done
 fi
 if [ "$STAGE" = a ]; then exit 0; fi
 step 300 "$OUT/attention_bench.txt" python -u tools/attention_bench.py || exit 1
 step 300 "$OUT/norm_bench.txt" python -u tools/norm_bench.py || exit 1
 step 600 "$OUT/bench_train.json.log" python -u bench.py --train || exit 1
-LDM_WT_STORES=1 step 600 "$OUT/bench_train_wt.json.log" python -u bench.py --train || exit 1
 step 600 "$OUT/bench_strong.json.log" python -u bench.py --strong || exit 1
 bash tools/profile_bench.sh "$OUT/prof" r3
