@@ -103,6 +103,14 @@ int ldm_train_input_prep(const float* moments, const float* eps, float* noise, c
 int ldm_cond_dropout(void* enc, const void* null_emb, const unsigned char* drop, int dtype, int batch, int64_t per_sample,
                      void* stream);
 
+/* N(0,1) noise for rows [row0, row0 + rows) of a batch whose rows have row_elems elements, float32, as a function of
+ * (seed, step, GLOBAL row index, element) only: Philox4x32-10 keyed by seed, counter = (element / 4, row, step + 1), Box-Muller
+ * on 23-bit uniforms.  Replaces `torch.randn_like(mean)` of DDPMScheduler.step (scheduling_ddpm.py:212, global RNG) and the
+ * initial `randn` of generate (train_latent_diffusion.py:566-576) in the batch-sharded sampler (ldm/sampling.py): a rank draws
+ * only its own rows and the values of a row do not depend on the number of ranks.  step = -1: the initial latents.
+ * The reference's own noise stream (torch's global generator) is NOT reproduced; parity tests inject identical noise tensors. */
+int ldm_gaussian_noise(uint64_t seed, int64_t step, int64_t row0, int64_t rows, int64_t row_elems, float* out, void* stream);
+
 /* ------------------------------------------------------------------------- UNet: weight packing */
 
 /* dst[o'][kh][kw][ci] = src[o][ci][kh][kw] (src float32 OIHW / [out,in]; dst dtype LDM_BF16 or LDM_F32).

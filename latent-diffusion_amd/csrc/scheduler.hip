@@ -328,6 +328,54 @@ static int step_common(const void* eu, const void* ec, bool cfg, int eps_dtype, 
   return launch_step<bf16_t, bf16_t>(eu, ec, cfg, g, x, noise, prev, x0, n, coef, st);
 }
 
+// ------------------------------------------------------------------------------- per-sample Gaussian noise
+// Counter-based N(0,1) draws keyed by the GLOBAL sample index (noise must be a function of (seed, step, sample),
+// not of the shard): Philox4x32-10 (Salmon et al., SC'11) with key = seed and counter = (block of four elements inside the
+// sample, sample index lo / hi, step + 1); the four 32-bit outputs become two Box-Muller pairs.  A rank draws ONLY its rows;
+// a row's values are the same on any rank of any world size.  oracle/noise_ref.py restates the same function in numpy.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+gaussian_rows_kernel(uint32_t seed_lo, uint32_t seed_hi, uint32_t step1, int64_t row0, int64_t rows, int64_t row_elems,
+                     float* __restrict__ out) {
+  const int64_t quads = (row_elems + 3) >> 2;
+  const int64_t total = rows * quads;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / quads, q = i - r * quads;
+    const uint64_t grow = (uint64_t)(row0 + r);
+    uint32_t c[4] = {(uint32_t)q, (uint32_t)grow, (uint32_t)(grow >> 32), step1};
+    philox4x32_10(c, seed_lo, seed_hi);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // 23 random bits + 1/2 in (0, 1): exact in float32 on every host and device
+      const float u0 = ((float)(c[2 * h] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+      const float u1 = ((float)(c[2 * h + 1] >> 9) + 0.5f) * 1.1920928955078125e-07f;
+      const float rad = sqrtf(-2.0f * logf(u0));
+      float sn, cs;
+      sincosf(6.283185307179586f * u1, &sn, &cs);
+      z[2 * h] = rad * cs;
+      z[2 * h + 1] = rad * sn;
+    }
+    float* o = out + r * row_elems + q * 4;
+    if (q * 4 + 4 <= row_elems && (row_elems & 3) == 0) {
+      *reinterpret_cast<float4*>(o) = make_float4(z[0], z[1], z[2], z[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (q * 4 + e < row_elems) o[e] = z[e];
+    }
+  }
+}
+
 }  // namespace ldm
 
 extern "C" int ldm_ddpm_step(const void* eps, int eps_dtype, const void* x_t, int x_dtype, const float* noise,
@@ -398,5 +446,20 @@ extern "C" int ldm_cond_dropout(void* enc, const void* null_emb, const unsigned 
   else
     hipLaunchKernelGGL((cond_dropout_kernel<float>), dim3(gx, batch), dim3(256), 0, st, (float*)enc, (const float*)null_emb, drop, per_sample);
   LDM_HIP_CHECK_LAUNCH("ldm_cond_dropout");
+  return LDM_OK;
+}
+
+extern "C" int ldm_gaussian_noise(uint64_t seed, int64_t step, int64_t row0, int64_t rows, int64_t row_elems, float* out,
+                                  void* stream) {
+  LDM_REQUIRE(rows >= 0 && row_elems >= 0 && row0 >= 0 && step >= -1 && step < 0xfffffffeLL, "ldm_gaussian_noise: bad sizes");
+  if (rows == 0 || row_elems == 0) return LDM_OK;
+  LDM_REQUIRE(out != nullptr && aligned16(out), "ldm_gaussian_noise: out must be a 16-byte aligned device pointer");
+  LDM_REQUIRE((row_elems + 3) / 4 < (1LL << 32), "ldm_gaussian_noise: rows longer than 2^34 elements");
+  const int64_t total = rows * ((row_elems + 3) / 4);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(gaussian_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (uint32_t)(step + 1), row0, rows, row_elems, out);
+  LDM_HIP_CHECK_LAUNCH("ldm_gaussian_noise");
   return LDM_OK;
 }

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "ldm_train_input_prep": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_i64,
                              C.c_float, C.c_float, C.c_float, c_void_p, c_void_p, c_void_p],
     "ldm_cond_dropout": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64, c_void_p],
+    "ldm_gaussian_noise": [C.c_uint64, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p],
     "ldm_pack_weight_pair": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.c_longlong, c_void_p],
     "ldm_add": [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_int, C.c_longlong, c_int, c_void_p],
     "ldm_silu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_void_p],

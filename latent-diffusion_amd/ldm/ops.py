@@ -814,6 +814,24 @@ def silu(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gaussian_noise(seed: int, step: int, row0: int, rows: int, row_shape, device) -> torch.Tensor:
+    """float32 (rows, *row_shape) N(0,1) noise of global samples [row0, row0 + rows) at `step` (-1: the initial latents): a
+    function of (seed, step, global sample index, element) only (ldm_gaussian_noise, Philox4x32-10 + Box-Muller), so a
+    batch-sharded sampler draws just its rows and gets the same rows on any number of ranks."""
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("ldm_amd: gaussian_noise draws on an AMD GPU (there is no CPU fallback)")
+    row_elems = 1
+    for d in row_shape:
+        row_elems *= int(d)
+    out = torch.empty((rows, *row_shape), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.load().ldm_gaussian_noise(int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), int(row0), int(rows), row_elems,
+                                                  out.data_ptr(), torch.cuda.current_stream(device).cuda_stream),
+                   "ldm_gaussian_noise")
+    return out
+
+
 # ----------------------------------------------------------------------------- VAE-decoder leg (SURVEY 8f-2)
 def softmax_rows(scores: torch.Tensor, valid_cols: int, scale: float, out_dtype: torch.dtype) -> torch.Tensor:
     """scores: float32 (rows, cols).  softmax(scale * scores) over the first valid_cols columns, zeros after."""

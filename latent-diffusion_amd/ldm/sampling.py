@@ -7,9 +7,10 @@ denoiser forward (two batched forwards' worth with classifier-free guidance, :58
 
 Multi-GPU: every latent is independent through all steps, so rank g of G owns the contiguous slice
 ``shard_range(N, g, G)`` of the batch and the loop contains NO collective.  So that the result does not depend on G,
-the initial latents and the per-step noise are functions of (seed, step, global sample index): each rank draws the
-step's noise for the whole batch from a generator seeded by (seed, step) and keeps its rows (4 M floats at N = 256,
-negligible beside a forward).  ``gather_latents`` is the optional final all-gather.
+the initial latents and the per-step noise are functions of (seed, step, global sample index, element): a counter-based
+generator (``ldm_gaussian_noise``: Philox4x32-10 keyed by the seed, counter = element block / sample / step) from which a
+rank draws ONLY its own rows -- nothing is drawn for the other ranks' samples.  ``gather_latents`` is the optional final
+all-gather.
 """
 from __future__ import annotations
 
@@ -27,24 +28,20 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def _seed_for(seed: int, step: int) -> int:
-    # distinct, reproducible 63-bit seeds per (seed, step); step -1 = initial latents
-    return (seed * 1_000_003 + (step + 1) * 7_919 + 0x5DEECE66D) & 0x7FFF_FFFF_FFFF_FFFF
-
-
 def global_noise(seed: int, step: int, shape, lo: int, hi: int, device, dtype=torch.float32) -> torch.Tensor:
-    """Rows [lo, hi) of the N(0,1) tensor of `shape` (shape[0] = global batch) that belongs to (seed, step).
-    Drawn on `device` for the whole batch, so the values of a row do not depend on how the batch is sharded."""
-    g = torch.Generator(device=device).manual_seed(_seed_for(seed, step))
-    full = torch.randn(tuple(shape), generator=g, device=device, dtype=dtype)
-    return full[lo:hi].contiguous()
+    """Rows [lo, hi) of the N(0,1) tensor of `shape` (shape[0] = global batch) that belongs to (seed, step); only those rows
+    are drawn (ops.gaussian_noise).  step = -1: the initial latents."""
+    from . import ops
+    z = ops.gaussian_noise(seed, step, lo, hi - lo, tuple(shape[1:]), device)
+    return z if dtype == torch.float32 else z.to(dtype)
 
 
 @torch.inference_mode()
 def sample_latents(denoiser: Callable, scheduler, ctx: torch.Tensor, *, latent_shape=(4, 64, 64),
                    num_inference_steps: int = 50, guidance_scale: Optional[float] = None,
                    uncond_ctx: Optional[torch.Tensor] = None, seed: int = 0, rank: int = 0, world: int = 1,
-                   device=None, latent_dtype: torch.dtype = torch.float32, micro_batch: Optional[int] = None) -> torch.Tensor:
+                   device=None, latent_dtype: torch.dtype = torch.float32, micro_batch: Optional[int] = None,
+                   noise_fn: Optional[Callable] = None) -> torch.Tensor:
     """Run the reverse loop for this rank's shard of the batch and return its final latents (hi-lo, C, H, W).
 
     ctx: (N, S, D) conditioning of the WHOLE batch (each rank slices its rows).  With ``guidance_scale`` the
@@ -52,28 +49,31 @@ def sample_latents(denoiser: Callable, scheduler, ctx: torch.Tensor, *, latent_s
     combine eps_u + g (eps_c - eps_u) (:592) runs inside the scheduler's fused step kernel.
     micro_batch: run the shard as independent chunks of at most this many latents (each through all steps); the result
     is the same, the activations stay small (a 256-latent shard in one batch would pass the kernels' 2 GiB operands).
+    noise_fn(seed, step, shape, lo, hi, device, dtype): the noise source, default ``global_noise`` (the HIP generator); the
+    host-logic tests, which run this loop on CPU tensors with a stand-in denoiser, pass the oracle's restatement of it.
     """
+    noise_fn = noise_fn or global_noise
     n = ctx.shape[0]
     lo, hi = shard_range(n, rank, world)
     if micro_batch is not None and hi - lo > micro_batch:
         parts = []
         for c0 in range(lo, hi, micro_batch):
             parts.append(_sample_rows(denoiser, scheduler, ctx, c0, min(c0 + micro_batch, hi), latent_shape, num_inference_steps,
-                                      guidance_scale, uncond_ctx, seed, device, latent_dtype))
+                                      guidance_scale, uncond_ctx, seed, device, latent_dtype, noise_fn))
         return torch.cat(parts, dim=0)
     return _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_steps, guidance_scale, uncond_ctx, seed,
-                        device, latent_dtype)
+                        device, latent_dtype, noise_fn)
 
 
 def _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_steps, guidance_scale, uncond_ctx, seed, device,
-                 latent_dtype):
+                 latent_dtype, noise_fn):
     """The reverse loop for global rows [lo, hi)."""
     n = ctx.shape[0]
     device = device if device is not None else ctx.device
     my_ctx = ctx[lo:hi].to(device)
     scheduler.set_timesteps(num_inference_steps, device=device)
     shape = (n, *latent_shape)
-    latents = global_noise(seed, -1, shape, lo, hi, device, latent_dtype) * scheduler.init_noise_sigma
+    latents = noise_fn(seed, -1, shape, lo, hi, device, latent_dtype) * scheduler.init_noise_sigma
     if guidance_scale is not None:
         if uncond_ctx is None:
             raise ValueError("classifier-free guidance needs uncond_ctx ((1, S, D) or (N, S, D))")
@@ -81,7 +81,7 @@ def _sample_rows(denoiser, scheduler, ctx, lo, hi, latent_shape, num_inference_s
         unc = unc.expand(n, -1, -1)[lo:hi] if unc.shape[0] == 1 else unc[lo:hi]
         both_ctx = torch.cat([unc, my_ctx], dim=0)
     for i, t in enumerate(scheduler.timesteps):
-        noise = global_noise(seed, i, shape, lo, hi, device, torch.float32)
+        noise = noise_fn(seed, i, shape, lo, hi, device, torch.float32)
         if guidance_scale is None:
             eps = denoiser(scheduler.scale_model_input(latents, t), t, my_ctx)
             latents = scheduler.step(eps, t, latents, noise=noise).prev_sample

@@ -43,6 +43,17 @@ class OracleScheduler:
         return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
 
 
+def oracle_noise(seed, step, shape, lo, hi, device, dtype=torch.float32):
+    """The product's noise source (ldm_gaussian_noise, a HIP kernel) restated by the oracle: same function of
+    (seed, step, global row, element), drawn for rows [lo, hi) only."""
+    from oracle import noise_ref
+    row_elems = 1
+    for d in shape[1:]:
+        row_elems *= int(d)
+    z = torch.from_numpy(noise_ref.gaussian_rows(seed, step, lo, hi - lo, row_elems)).reshape(hi - lo, *shape[1:])
+    return z.to(dtype)
+
+
 def toy_denoiser(x, t, ctx):
     # per-sample arithmetic only, like the UNet (no batch-coupled op)
     return 0.1 * torch.tanh(x) + ctx.mean(dim=(1, 2)).reshape(-1, 1, 1, 1) * 0.01 + float(t) * 1e-4
@@ -55,7 +66,7 @@ def run_sampler(rank, world, n, steps, guidance):
     unc = torch.randn(1, 5, 8, generator=g)
     return sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, latent_shape=(4, 6, 6), num_inference_steps=steps,
                                    guidance_scale=guidance, uncond_ctx=unc if guidance else None, seed=3, rank=rank,
-                                   world=world, device=torch.device("cpu"))
+                                   world=world, device=torch.device("cpu"), noise_fn=oracle_noise)
 
 
 def _worker(rank, world, port, n, steps, guidance, out_dir):
@@ -91,10 +102,12 @@ def test_shard_range_partitions():
 
 def test_noise_is_independent_of_the_sharding():
     from ldm import sampling
-    full = sampling.global_noise(11, 4, (9, 4, 3, 3), 0, 9, torch.device("cpu"))
-    parts = [sampling.global_noise(11, 4, (9, 4, 3, 3), *sampling.shard_range(9, r, 4), torch.device("cpu")) for r in range(4)]
+    full = oracle_noise(11, 4, (9, 4, 3, 3), 0, 9, torch.device("cpu"))
+    parts = [oracle_noise(11, 4, (9, 4, 3, 3), *sampling.shard_range(9, r, 4), torch.device("cpu")) for r in range(4)]
     assert torch.equal(torch.cat(parts), full)
-    assert not torch.equal(full, sampling.global_noise(11, 5, (9, 4, 3, 3), 0, 9, torch.device("cpu")))
+    assert not torch.equal(full, oracle_noise(11, 5, (9, 4, 3, 3), 0, 9, torch.device("cpu")))
+    with pytest.raises(RuntimeError):      # the product's generator is a HIP kernel: no CPU fallback
+        sampling.global_noise(11, 4, (9, 4, 3, 3), 0, 9, torch.device("cpu"))
 
 
 @pytest.mark.parametrize("guidance", [None, 7.5])
@@ -112,7 +125,7 @@ def test_micro_batches_match_the_whole_shard():
     from ldm import sampling
     g = torch.Generator().manual_seed(7)
     ctx = torch.randn(7, 5, 8, generator=g)
-    kw = dict(latent_shape=(4, 6, 6), num_inference_steps=4, seed=3, device=torch.device("cpu"))
+    kw = dict(latent_shape=(4, 6, 6), num_inference_steps=4, seed=3, device=torch.device("cpu"), noise_fn=oracle_noise)
     whole = sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, **kw)
     for mb in (1, 3, 7, 100):
         assert torch.equal(sampling.sample_latents(toy_denoiser, OracleScheduler(), ctx, micro_batch=mb, **kw), whole)

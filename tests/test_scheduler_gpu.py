@@ -230,3 +230,28 @@ def test_s5_methods_on_device(golden, schedule):
     x0p = sch.predict_start_from_noise(x_t, tt, nz)
     mean, std = sch.q_posterior_between(x0p, x_t, tt, ss)
     assert rel_l2(out.prev_sample, mean + std * x0) < 1e-6
+
+
+def test_gaussian_noise_kernel_matches_the_oracle_and_ignores_the_sharding():
+    """ldm_gaussian_noise (Philox4x32-10 + Box-Muller keyed by the global sample index): integer part bit-exact by construction,
+    the float32 transcendental functions of device and host agree to 2e-6 absolute; rows drawn by a shard are BIT-equal to the
+    same rows of the whole batch (what makes the sharded sampler independent of the number of GPUs)."""
+    import numpy as np
+    from ldm import ops, sampling
+    from oracle import noise_ref
+    dev = torch.device("cuda")
+    seed, step, shape = 0x1234_5678_9ABC_DEF0, 17, (4, 64, 64)
+    full = ops.gaussian_noise(seed, step, 0, 32, shape, dev)
+    ref = torch.from_numpy(noise_ref.gaussian_rows(seed, step, 0, 32, 4 * 64 * 64)).reshape(32, *shape)
+    assert float((full.cpu() - ref).abs().max()) < 2e-6
+    part = ops.gaussian_noise(seed, step, 11, 5, shape, dev)
+    assert same_bits(part, full[11:16])
+    assert same_bits(sampling.global_noise(seed, step, (32, *shape), 11, 16, dev), part)
+    assert not torch.equal(ops.gaussian_noise(seed, step + 1, 11, 5, shape, dev), part)
+    z = ops.gaussian_noise(3, -1, 1000, 3, (7,), dev)          # ragged rows, initial-latent step
+    assert float((z.cpu() - torch.from_numpy(noise_ref.gaussian_rows(3, -1, 1000, 3, 7))).abs().max()) < 2e-6
+    big = ops.gaussian_noise(9, 0, 0, 256, shape, dev)
+    assert abs(float(big.mean())) < 2e-3 and abs(float(big.std()) - 1.0) < 2e-3 and torch.isfinite(big).all()
+    assert ops.gaussian_noise(9, 0, 5, 0, shape, dev).shape == (0, *shape)
+    with pytest.raises(RuntimeError):
+        ops.gaussian_noise(9, 0, 0, 1, shape, torch.device("cpu"))
