@@ -749,7 +749,9 @@ class UNet(_HipModule):
         n = getattr(self, "micro_batch_streams", None)
         if n is None:
             n = int(os.environ.get("LDM_MICRO_BATCH_STREAMS", "1"))
-        if n <= 1 or B < 16 or B < 2 * n or torch.cuda.is_current_stream_capturing():
+        if n <= 1 or B < 16 or B < 2 * n:
+            return 1
+        if torch.cuda.is_current_stream_capturing() and not getattr(self, "_ldm_allow_capture_streams", False):
             return 1
         return n
 

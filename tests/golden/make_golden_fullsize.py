@@ -11,7 +11,9 @@ container by importing the REFERENCE (same two inert stand-ins as make_golden.py
 Every vector is checked against the oracle restatement while it is generated (abort on mismatch).  Data only.
   scheduler_s5.npz     the scheduler methods `step` does not call (S5) and the float64 beta schedules
 
-Run: python tests/golden/make_golden_fullsize.py [s5] [64] [96] [wellcond]
+  unet_default64_moderate.npz   configs[1]'s shape and the small net on the moderate-gate filler (round 3)
+
+Run: python tests/golden/make_golden_fullsize.py [s5] [64] [64m] [96] [wellcond]
 """
 from __future__ import annotations
 
@@ -80,6 +82,21 @@ def gen_default64():
     one_case("p", {}, 3, dict(gain=1.0), x, t, ctx, out)
     one_case("w", {}, 3, WELL, x, t, ctx, out)
     save("unet_default64.npz", **out)
+
+
+def gen_default64_moderate():
+    """The same shape on oracle/unet_ref.MODERATE_GATE: a conditioned filler whose GELU gates stay non-linear."""
+    print("default UNet, B=2, 4x64x64, moderate-gate filler")
+    out = {}
+    x, ctx = seeded((2, 4, 64, 64), 181), seeded((2, 77, 768), 182)
+    t = torch.tensor([431, 37], dtype=torch.long)
+    out["t"] = t
+    one_case("m", {}, 3, uref.MODERATE_GATE, x, t, ctx, out)
+    small = {}
+    xs, cs = seeded((4, 4, 32, 32), 11), seeded((4, 77, 768), 12)
+    one_case("small_m", mg.SMALL, 7, uref.MODERATE_GATE, xs, torch.tensor([999, 500, 20, 0], dtype=torch.long), cs, small)
+    out.update(small)
+    save("unet_default64_moderate.npz", **out)
 
 
 def gen_default96():
@@ -192,6 +209,8 @@ if __name__ == "__main__":
         gen_wellcond()
     if "64" in which:
         gen_default64()
+    if "64m" in which:
+        gen_default64_moderate()
     if "96" in which:
         gen_default96()
     print("done")
