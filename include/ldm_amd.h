@@ -128,6 +128,22 @@ int ldm_pack_weight(const float* src, void* dst, int dst_dtype, int cout, int ci
 int ldm_pack_weight_pair(const float* src, void* fwd, void* dgrad, int dst_dtype, int cout, int cin, int kh, int kw,
                          int glu_pairs, long long dgrad_ld, void* stream);
 
+/* ldm_pack_weight_pair for MANY filters in one launch: the repack of every filter of the model that follows each optimizer step
+ * of the reference's train loop (train_latent_diffusion.py:1123-1126; autocast's per-step weight casts in the reference).  `jobs`
+ * is a DEVICE array of njobs descriptors, all bfloat16 destinations with the same tap count (1 or 9), cout, cin and dgrad_ld
+ * multiples of 4, 8-byte aligned destinations; first_block ascending from 0 with first_block[i+1] = first_block[i] +
+ * blocks_x[i] * blocks_y[i] (blocks_x = ceil(cout / 32), blocks_y = ceil(cin / 32)); total_blocks = their sum.  The caller
+ * validates the descriptors (ldm/ops.py pack_weight_pair_batch does); the kernel trusts them. */
+typedef struct LdmPackJob {
+  const float* src;   /* float32 [cout][cin][taps] */
+  void* fwd;          /* may be NULL */
+  void* dgrad;        /* may be NULL */
+  int64_t dgrad_ld;
+  int32_t cout, cin, glu_pairs;
+  int32_t blocks_x, blocks_y, first_block;
+} LdmPackJob;
+int ldm_pack_weight_pair_batch(const LdmPackJob* jobs_device, int njobs, int total_blocks, int taps, void* stream);
+
 /* ------------------------------------------------------------------- UNet: implicit-GEMM conv/linear */
 
 enum {

@@ -36,13 +36,12 @@ pack_weight_kernel(const float* __restrict__ src, T* __restrict__ dst, int cout,
 // global loads (4 / 36) are in flight before the first LDS store -- with a run-time count the loop was one load, one
 // store, one HBM latency per iteration, and the whole repack ran at 2 TB/s.
 template <typename T, bool VEC4, int TAPS>
-__global__ void __launch_bounds__(256)
-pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad, int cout, int cin, int taps_arg,
-                        int glu, long long dgrad_ld) {
+__device__ __forceinline__ void pack_weight_pair_body(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad,
+                                                      int cout, int cin, int taps_arg, int glu, long long dgrad_ld, int bx, int by) {
   extern __shared__ float tile[];                       // [32 o'][32*taps + 1]
   const int taps = TAPS ? TAPS : taps_arg;
   const int ost = 32 * taps + 1;
-  const int o0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int o0 = bx * 32, c0 = by * 32;
   const int half = cout >> 1;
   const int run = 32 * taps;                            // floats per source row segment
   auto fetch = [&](int i) {
@@ -123,6 +122,33 @@ pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* _
         Elem<T>::st(dgrad + ((long long)ci * taps + tp) * dgrad_ld + op, tile[ol * ost + cl * taps + (taps - 1 - tp)]);
     }
   }
+}
+
+template <typename T, bool VEC4, int TAPS>
+__global__ void __launch_bounds__(256)
+pack_weight_pair_kernel(const float* __restrict__ src, T* __restrict__ fwd, T* __restrict__ dgrad, int cout, int cin, int taps_arg,
+                        int glu, long long dgrad_ld) {
+  pack_weight_pair_body<T, VEC4, TAPS>(src, fwd, dgrad, cout, cin, taps_arg, glu, dgrad_ld, blockIdx.x, blockIdx.y);
+}
+
+// Every filter of a model in ONE launch (per tap count): the training step repacks all ~250 filters after each optimizer step,
+// and as 250 launches of a few microseconds each that cost more on the host (and in launch boundaries) than in the kernels.
+// Workgroup b finds its job by bisection over the jobs' first-block numbers (device table, ascending).
+template <int TAPS>
+__global__ void __launch_bounds__(256)
+pack_weight_pair_batch_kernel(const LdmPackJob* __restrict__ jobs, int njobs) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= b) lo = mid; else hi = mid - 1;
+  }
+  const LdmPackJob j = jobs[lo];
+  const int local = b - j.first_block;
+  const int by = local / j.blocks_x, bx = local - by * j.blocks_x;
+  if (by >= j.blocks_y) return;
+  pack_weight_pair_body<bf16_t, true, TAPS>(j.src, static_cast<bf16_t*>(j.fwd), static_cast<bf16_t*>(j.dgrad), j.cout, j.cin, TAPS,
+                                            j.glu_pairs, j.dgrad_ld, bx, by);
 }
 
 template <typename T>
@@ -525,6 +551,19 @@ extern "C" int ldm_pack_weight_pair(const float* src, void* fwd, void* dgrad, in
   }
 #undef LDM_PACK_PAIR
   LDM_HIP_CHECK_LAUNCH("ldm_pack_weight_pair");
+  return LDM_OK;
+}
+
+extern "C" int ldm_pack_weight_pair_batch(const LdmPackJob* jobs_device, int njobs, int total_blocks, int taps, void* stream) {
+  LDM_REQUIRE(njobs >= 0 && total_blocks >= 0, "ldm_pack_weight_pair_batch: bad sizes");
+  if (njobs == 0 || total_blocks == 0) return LDM_OK;
+  LDM_REQUIRE(jobs_device != nullptr, "ldm_pack_weight_pair_batch: null job table");
+  LDM_REQUIRE(taps == 1 || taps == 9, "ldm_pack_weight_pair_batch: taps must be 1 or 9 (got %d)", taps);
+  const size_t smem = (size_t)32 * (32 * taps + 1) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (taps == 1) hipLaunchKernelGGL((pack_weight_pair_batch_kernel<1>), dim3(total_blocks), dim3(256), smem, st, jobs_device, njobs);
+  else hipLaunchKernelGGL((pack_weight_pair_batch_kernel<9>), dim3(total_blocks), dim3(256), smem, st, jobs_device, njobs);
+  LDM_HIP_CHECK_LAUNCH("ldm_pack_weight_pair_batch");
   return LDM_OK;
 }
 

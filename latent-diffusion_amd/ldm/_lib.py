@@ -52,6 +52,13 @@ class ConvGemmDesc(C.Structure):
     ]
 
 
+class PackJob(C.Structure):
+    """struct LdmPackJob (include/ldm_amd.h)."""
+    _fields_ = [("src", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p), ("dgrad_ld", C.c_int64),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("glu_pairs", C.c_int32),
+                ("blocks_x", C.c_int32), ("blocks_y", C.c_int32), ("first_block", C.c_int32)]
+
+
 # name -> argtypes; every function returns int except the two noted below
 _SIGNATURES = {
     "ldm_ddpm_build_tables": [c_int, c_int, PF, PF, PF, PF, PF, PF, PF],
@@ -80,6 +87,7 @@ _SIGNATURES = {
     "ldm_cond_dropout": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_i64, c_void_p],
     "ldm_gaussian_noise": [C.c_uint64, c_i64, c_i64, c_i64, c_i64, c_void_p, c_void_p],
     "ldm_pack_weight_pair": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, C.c_longlong, c_void_p],
+    "ldm_pack_weight_pair_batch": [c_void_p, c_int, c_int, c_int, c_void_p],
     "ldm_add": [c_void_p, C.c_longlong, c_void_p, C.c_longlong, c_void_p, c_int, C.c_longlong, c_int, c_void_p],
     "ldm_silu_backward": [c_void_p, c_void_p, c_void_p, c_int, C.c_longlong, c_void_p],
     "ldm_groupnorm_backward": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

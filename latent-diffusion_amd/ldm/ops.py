@@ -73,9 +73,9 @@ def _rows3(what: str, t: torch.Tensor, dtype: torch.dtype, batch: int, rows: int
         raise ValueError(f"{what}: must be a row-strided (B, L, C) view with unit column stride (strides {t.stride()})")
 
 
-def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) -> torch.Tensor:
-    """float32 [O, I, kh, kw] or [O, I]  ->  [O', kh*kw*I] K-contiguous filter in `dtype`."""
-    _gpu(w)
+def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [O, I, kh, kw] or [O, I]  ->  [O', kh*kw*I] K-contiguous filter in `dtype` (into `out` when given)."""
+    _gpu(w, out)
     w = w.detach().to(torch.float32).contiguous()
     if w.dim() == 2:
         o, i, kh, kw = w.shape[0], w.shape[1], 1, 1
@@ -83,7 +83,10 @@ def pack_weight(w: torch.Tensor, dtype: torch.dtype, glu_pairs: bool = False) ->
         o, i, kh, kw = w.shape[0], 1, 1, 1
     else:
         o, i, kh, kw = w.shape
-    out = torch.empty((o, kh * kw * i), dtype=dtype, device=w.device)
+    if out is None:
+        out = torch.empty((o, kh * kw * i), dtype=dtype, device=w.device)
+    elif out.dtype != dtype or out.numel() != o * kh * kw * i or not out.is_contiguous():
+        raise ValueError("pack_weight: out must be a contiguous tensor of the packed size and dtype")
     with torch.cuda.device(w.device):
         _lib.check(_lib.load().ldm_pack_weight(w.data_ptr(), out.data_ptr(), dt_code(dtype), o, i, kh, kw,
                                                1 if glu_pairs else 0, _stream(w)), "ldm_pack_weight")
@@ -121,6 +124,68 @@ def pack_weight_pair(w: torch.Tensor, dtype: torch.dtype, *, glu_pairs: bool = F
     if dgrad is not None and dgrad.is_contiguous():
         dgrad = dgrad.view(i, kh * kw * o)          # the K-contiguous filter of the dgrad GEMM: N = Cin, K = taps * Cout
     return fwd, dgrad
+
+
+class PackPlan:
+    """The repack of MANY filters as one launch per tap count (ldm_pack_weight_pair_batch): the training step rebuilds every
+    derived filter after each optimizer step, ~250 of them.  ``jobs``: (w float32 checkpoint filter, fwd (O, K) row range,
+    dgrad (K, O) column range or None, glu_pairs).  The destinations are kept and rewritten in place by every ``run()``; jobs
+    the batch kernel does not take (float32 destinations, dimensions that are not multiples of 4) go through
+    pack_weight_pair one by one."""
+
+    def __init__(self, jobs, dtype: torch.dtype):
+        self.dtype = dtype
+        self.single = []
+        self.groups = {}                       # taps -> (device job table, njobs, total blocks)
+        self._keep = []                        # the tensors the device tables point into
+        by_taps = {1: [], 9: []}
+        for w, fwd, dgrad, glu in jobs:
+            _gpu(w, fwd, dgrad)
+            wd = w.detach()
+            o, i = wd.shape[0], wd.shape[1]
+            taps = 1 if wd.dim() == 2 else wd.shape[2] * wd.shape[3]
+            k = taps * i
+            ld = 0 if dgrad is None else dgrad.stride(0)
+            ok = (dtype == torch.bfloat16 and wd.dtype == torch.float32 and wd.is_contiguous() and taps in by_taps
+                  and o % 4 == 0 and i % 4 == 0 and ld % 4 == 0 and fwd.data_ptr() % 8 == 0
+                  and (dgrad is None or dgrad.data_ptr() % 8 == 0) and (not glu or o % 32 == 0))
+            if fwd.shape != (o, k) or not fwd.is_contiguous() or fwd.dtype != dtype:
+                raise ValueError("PackPlan: fwd must be a contiguous (O, K) row range in the packed dtype")
+            if dgrad is not None and (dgrad.shape != (k, o) or dgrad.stride(1) != 1 or dgrad.dtype != dtype):
+                raise ValueError("PackPlan: dgrad must be a (K, O) column range with unit column stride")
+            self._keep.append((w, fwd, dgrad))
+            if ok:
+                by_taps[taps].append((wd, fwd, dgrad, glu, o, i, ld))
+            else:
+                self.single.append((w, fwd, dgrad, glu))
+        for taps, lst in by_taps.items():
+            if not lst:
+                continue
+            arr = (_lib.PackJob * len(lst))()
+            first = 0
+            for n, (wd, fwd, dgrad, glu, o, i, ld) in enumerate(lst):
+                bx, by = (o + 31) // 32, (i + 31) // 32
+                arr[n] = _lib.PackJob(src=wd.data_ptr(), fwd=fwd.data_ptr(), dgrad=_ptr(dgrad), dgrad_ld=ld, cout=o, cin=i,
+                                      glu_pairs=1 if glu else 0, blocks_x=bx, blocks_y=by, first_block=first)
+                first += bx * by
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            table = host.to(lst[0][0].device)
+            self.groups[taps] = (table, len(lst), first)
+        self.sources = tuple(w.data_ptr() for w, _, _ in self._keep)
+
+    def run(self):
+        lib = _lib.load()
+        for taps, (table, n, blocks) in self.groups.items():
+            with torch.cuda.device(table.device):
+                _lib.check(lib.ldm_pack_weight_pair_batch(table.data_ptr(), n, blocks, taps,
+                                                          torch.cuda.current_stream(table.device).cuda_stream),
+                           "ldm_pack_weight_pair_batch")
+        for w, fwd, dgrad, glu in self.single:
+            pack_weight_pair(w, self.dtype, glu_pairs=glu, fwd=fwd, dgrad=dgrad, want_dgrad=dgrad is not None)
+
+    def still_valid(self) -> bool:
+        """The checkpoint tensors the device tables point at have not moved (optimizers update parameters in place)."""
+        return self.sources == tuple(w.data_ptr() for w, _, _ in self._keep)
 
 
 def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,

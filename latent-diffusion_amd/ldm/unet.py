@@ -74,15 +74,53 @@ def param_state_key(module: nn.Module):
     return (_optimizer_steps[0], tuple((p._version, p.data_ptr()) for p in module.parameters()))
 
 
+class Repack:
+    """What ``pack_tree(train=True)`` leaves under ``P["_repack"]``: everything needed to rewrite the derived tensors IN PLACE
+    after an optimizer step -- the batched filter pack (``ops.PackPlan``, one launch per tap count instead of one per filter)
+    and the few derived copies that are not filters (packed GLU biases, the fused time-projection bias, casts of parameters
+    that are not float32)."""
+
+    def __init__(self, plan, refresh):
+        self.plan, self.refresh = plan, refresh
+
+    def run(self):
+        self.plan.run()
+        with torch.no_grad(), torch.autocast("cuda", enabled=False):
+            for f in self.refresh:
+                f()
+
+    def still_valid(self) -> bool:
+        return self.plan.still_valid()
+
+
 def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
     """Derived, K-contiguous copies of every filter under ``root`` in the compute dtype, keyed by module path.
     Checkpoint layout stays PyTorch's ([out, in, kh, kw]); these are rebuilt when a parameter changes.
     train: also the filters of the input-gradient pass (``.wd``: in/out transposed, taps rotated), produced by the same
-    pass over the checkpoint tensor (ldm_pack_weight_pair)."""
+    pass over the checkpoint tensor -- all filters of the tree in one batched launch per tap count (``ops.PackPlan``), which
+    ``P["_repack"].run()`` repeats in place after every optimizer step."""
     P = {}
+    jobs = []           # train: (checkpoint filter, fwd destination, dgrad destination, glu_pairs)
+    refresh = []        # train: closures that rewrite the derived NON-filter copies in place
 
     def f32(p):
-        return p.detach().to(torch.float32).contiguous()
+        t = p.detach().to(torch.float32).contiguous()
+        if t.data_ptr() != p.data_ptr():          # a real copy (parameter not float32 / not dense): must follow the parameter
+            refresh.append(lambda t=t, p=p: t.copy_(p.detach()))
+        return t
+
+    def pair(w, glu=False, fwd=None, dgrad=None):
+        """(fwd, dgrad-as-filter) of one checkpoint filter; packed now (inference) or by the batched plan (train)."""
+        wd_ = w.detach()
+        o, i = wd_.shape[0], wd_.shape[1]
+        taps = 1 if wd_.dim() == 2 else wd_.shape[2] * wd_.shape[3]
+        k = taps * i
+        if fwd is None:
+            fwd = torch.empty((o, k), dtype=dtype, device=w.device)
+        if dgrad is None:
+            dgrad = torch.empty((k, o), dtype=dtype, device=w.device)
+        jobs.append((w, fwd, dgrad, glu))
+        return fwd, (dgrad.view(i, taps * o) if dgrad.is_contiguous() else dgrad)
 
     def pack_fused(key, weights):
         """Several filters sharing their input, stacked along the output dimension, as one filter."""
@@ -94,13 +132,16 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
         r = 0
         for w in weights:
             n = w.shape[0]
-            ops.pack_weight_pair(w, dtype, fwd=fwd[r:r + n], dgrad=None if dg is None else dg[:, r:r + n], want_dgrad=train)
+            if train:
+                pair(w, fwd=fwd[r:r + n], dgrad=dg[:, r:r + n])
+            else:
+                ops.pack_weight_pair(w, dtype, fwd=fwd[r:r + n], dgrad=None, want_dgrad=False)
             r += n
         P[key + ".w"] = fwd
         if train:
             P[key + ".wd"] = dg
 
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast("cuda", enabled=False):   # packing may run inside the caller's autocast region
         for name, mod in root.named_modules():
             if getattr(mod, "_ldm_raw", False):       # conv_in / final conv keep float32 OIHW filters
                 P[name + ".w"] = f32(mod.weight)
@@ -110,12 +151,16 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
             elif isinstance(mod, (nn.Conv2d, nn.Linear)):
                 glu = name.endswith("w1_w2")
                 if train:
-                    P[name + ".w"], P[name + ".wd"] = ops.pack_weight_pair(mod.weight, dtype, glu_pairs=glu)
+                    P[name + ".w"], P[name + ".wd"] = pair(mod.weight, glu)
                 else:
                     P[name + ".w"] = ops.pack_weight(mod.weight, dtype, glu_pairs=glu)
                 if mod.bias is not None:
-                    P[name + ".b"] = ops.pack_weight(mod.bias, torch.float32, glu_pairs=True).flatten() if glu \
-                        else f32(mod.bias)
+                    if glu:
+                        gb = ops.pack_weight(mod.bias, torch.float32, glu_pairs=True)
+                        refresh.append(lambda gb=gb, bias=mod.bias: ops.pack_weight(bias, torch.float32, glu_pairs=True, out=gb))
+                        P[name + ".b"] = gb.flatten()
+                    else:
+                        P[name + ".b"] = f32(mod.bias)
             elif isinstance(mod, (nn.GroupNorm, nn.LayerNorm)):
                 P[name + ".g"] = f32(mod.weight)
                 P[name + ".b"] = f32(mod.bias)
@@ -143,7 +188,10 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
         if isinstance(root, UNet) and resnets:
             # all time projections (unet.py:703) as one filter; each resnet reads its column slice
             pack_fused("time_all", [m.time[1].weight for _, m in resnets])
-            P["time_all.b"] = f32(torch.cat([m.time[1].bias for _, m in resnets], 0))
+            tb = torch.cat([m.time[1].bias.detach().to(torch.float32) for _, m in resnets], 0)
+            refresh.append(lambda tb=tb, ms=[m for _, m in resnets]:
+                           torch.cat([m.time[1].bias.detach().to(torch.float32) for m in ms], 0, out=tb))
+            P["time_all.b"] = tb
             off = 0
             for n, m in resnets:
                 P[n + ".time_off"] = off
@@ -158,6 +206,10 @@ def pack_tree(root: nn.Module, dtype: torch.dtype, train: bool = False) -> dict:
             for n, m in cross:
                 P[n + ".kv_off"] = off
                 off += m.kv_proj.weight.shape[0]
+        if train:
+            plan = ops.PackPlan(jobs, dtype)
+            plan.run()
+            P["_repack"] = Repack(plan, refresh)
     return P
 
 
@@ -182,8 +234,15 @@ class _HipModule(nn.Module):
         ver = param_state_key(self)
         cache = self.__dict__.setdefault("_ldm_cache", {})
         if cache.get("ver") != ver:
+            # a parameter changed.  The training set of the dtype being asked for is rewritten IN PLACE by its batched repack
+            # (same buffers, two launches) when the parameters still live where its job tables point; everything else is dropped.
+            kept = cache.get((dtype, True)) if train else None
+            rp = kept.get("_repack") if kept is not None else None
             cache.clear()
             cache["ver"] = ver
+            if rp is not None and rp.still_valid():
+                rp.run()
+                cache[(dtype, True)] = kept
         key = (dtype, train)
         if key not in cache:
             if train and (dtype, False) in cache:
