@@ -117,20 +117,29 @@ def pmc_traffic(kernel: str, workload_key: str):
 
 def roofline_from_log(log, elapsed, workload_key):
     per = {}
-    for name, flops, e0, e1, _shape in log:
-        d = per.setdefault(name, [0, 0.0, 0.0])
+    for name, flops, e0, e1, shape in log:
+        d = per.setdefault(name, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += flops
         d[2] += e0.elapsed_time(e1) * 1e-3
+        # algorithmic HBM bytes of the launch: the input activation once (not once per tap or per tile column), the filter,
+        # the output, and the residual operand when the epilogue adds one (bf16; the GLU output is half as wide)
+        m, n, k, ksize, stride, up, _c1, epi = shape
+        cin = k // (ksize * ksize)
+        in_pix = m * stride * stride / (4 if up else 1)
+        nout = n // 2 if epi & 48 else n
+        d[3] += 2.0 * (in_pix * cin + n * k + m * nout + (m * n if epi & 4 else 0))
     gemm_time = sum(d[2] for d in per.values())
     dom = max(per, key=lambda k: per[k][2])
-    n_l, fl, tt = per[dom]
+    n_l, fl, tt, ab = per[dom]
     achieved = fl / tt
     traffic, note = pmc_traffic(dom, workload_key)
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved / 1e12, 1), "peak": MFMA_BF16_DENSE_PEAK / 1e12,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_DENSE_PEAK, 4), "traffic": traffic, "traffic_note": note,
             "launches": n_l, "avg_launch_us": round(1e6 * tt / n_l, 1),
             "algorithmic_gflop_per_launch": round(fl / n_l / 1e9, 2),
+            "algorithmic_MB_per_launch": round(ab / n_l / 1e6, 1),
+            "traffic_over_algorithmic_bytes": None if traffic is None else round(traffic / (ab / n_l), 2),
             "all_gemm_kernels": {k: {"launches": v[0], "tflops": round(v[1] / v[2] / 1e12, 1),
                                      "avg_us": round(1e6 * v[2] / v[0], 1)} for k, v in sorted(per.items())}}
     return roof, gemm_time / elapsed
