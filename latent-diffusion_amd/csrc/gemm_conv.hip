@@ -100,7 +100,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* base, unsigned bytes, u
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int PP = 0>
 __global__ void __launch_bounds__(64 * WM * WN, 2)
 conv_gemm_bf16_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
@@ -381,6 +381,115 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     if (nk > 1) stage(1, kt_begin + 1);
     ln_finish();
     int slot = 0;
+    if constexpr (PP) {
+      // Ping-pong form of the ring: the waves of a workgroup are two groups of WM*WN/2, one wave of each per SIMD.  A
+      // K-tile is two phases; in each, one group only issues its MFMAs (all fragments of the K-tile already in registers)
+      // while the other reads its fragments of the next tile from LDS and issues its share of the LDS-DMA of the tile
+      // after next; a workgroup barrier swaps the roles.  The matrix cores of a SIMD then always have one wave that does
+      // nothing but feed them, and the barrier wait / staging arithmetic / fragment reads of the other wave run under it
+      // (in the plain ring both waves of a SIMD reach the barrier and the staging code together: per K-tile ~2,200 cycles
+      // for 1,280 of matrix-core time).
+      //   group 0:  R(kt)   | M(kt)   | R(kt+1) | M(kt+1) ...        R = fragment reads + DMA issue, M = MFMAs
+      //   group 1:  M(kt-1) | R(kt)   | M(kt)   | R(kt+1) ...
+      // Tile kt is read in phases 2kt (group 0) and 2kt+1 (group 1); its slot is refilled with tile kt+3 from phase
+      // 2kt+2 on; every wave waits for its own DMA of tile kt+1 before the barrier that ends phase 2kt+1.
+      static_assert((WM * WN) % 2 == 0, "two wave groups");
+      bf16x8_t af[KS][MI], bfr[KS][NI];
+#ifdef LDM_GEMM_STAMPS
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[ks][i] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bfr[ks][j] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+#endif
+      auto read_frags = [&](int buf) {
+        const unsigned char* sa = smem + buf * STAGE;
+        const unsigned char* sb = sa + A_BYTES;
+        if (LDM_ABLATE(4)) return;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int row = wm * WTM + i * 16 + fr;
+            af[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+          }
+#pragma unroll
+          for (int j = 0; j < NI; ++j) {
+            const int row = wn * WTN + j * 16 + fr;
+            bfr[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + row * ROWB + (((ks * 4 + fq) ^ swz<CH>(row)) << 4));
+          }
+        }
+      };
+      auto mfma_all = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (!LDM_ABLATE(2))
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto pp_stage = [&](int buf, int kt) {
+        if (LDM_ABLATE(8)) return;
+        if (LDM_ABLATE(1)) { stage_begin(buf, kt); return; }
+        stage(buf, kt);
+      };
+      // all of this wave's LDS-DMA has landed except the batch issued last (when one more tile was staged)
+      auto wait_older_dma = [&](bool newer_in_flight) {
+        if (LDM_ABLATE(9)) return;
+        if (newer_in_flight) {
+          if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_FULL + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_FULL) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      };
+      auto barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      wait_older_dma(nk > 1);                 // tile 0 (tile 1 may still be in flight)
+      barrier();
+      if (wave < WM * WN / 2) {
+        for (int kt = 0; kt < nk; ++kt) {
+          if (kt == 8) LDM_STAMP(8);
+          read_frags(slot);
+          const bool more = kt + 2 < nk;
+          if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (kt == 8) LDM_STAMP(9);
+          barrier();
+          if (kt == 8) LDM_STAMP(10);
+          mfma_all();
+          wait_older_dma(more);
+          if (kt == 8) LDM_STAMP(11);
+          barrier();
+          slot = slot == 2 ? 0 : slot + 1;
+        }
+      } else {
+        for (int kt = 0; kt < nk; ++kt) {
+          if (kt > 0) mfma_all();
+          barrier();
+          read_frags(slot);
+          const bool more = kt + 2 < nk;
+          if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          wait_older_dma(more);
+          barrier();
+          slot = slot == 2 ? 0 : slot + 1;
+        }
+        mfma_all();
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) {
         if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_IT + B_FULL + 1) : "memory");
@@ -835,12 +944,12 @@ conv_gemm_f32_kernel(const ConvGemmParams p) {
 static unsigned long long* g_stamp_buf = nullptr;
 static long long g_stamp_blocks = 0;
 #endif
-template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES = 2, int PP = 0>
 static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const int smem = STAGES * (BM + BN) * BK * 2;
-  auto kern = conv_gemm_bf16_kernel<BM, BN, BK, WM, WN, STAGES>;
+  auto kern = conv_gemm_bf16_kernel<BM, BN, BK, WM, WN, STAGES, PP>;
   static bool attr_done = false;  // opt in to > 64 KiB of dynamic LDS once per instantiation
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -858,6 +967,12 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
     LDM_HIP_CHECK_LAUNCH("ldm_conv_gemm(split-K fold)");
   }
   return LDM_OK;
+}
+
+// LDM_GEMM_PINGPONG=0/1: the plain ring or its ping-pong form for the 256-row tiles (read per call: A/B runs in one process)
+static bool pingpong() {
+  const char* e = getenv("LDM_GEMM_PINGPONG");
+  return e ? atoi(e) != 0 : false;
 }
 
 // Expected efficiency of a (tile, split-K) choice: padding waste x chip fill x operand reuse x split-K overhead.
@@ -1048,8 +1163,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     case 64128064: return launch_bf16<64, 128, 64, 2, 2>(p, st);
     case 128160064: return launch_bf16<128, 160, 64, 2, 2>(p, st);
     case 64160064: return launch_bf16<64, 160, 64, 2, 2>(p, st);
-    case 256160064: return launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
-    case 256128064: return launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
+    case 256160064: return pingpong() ? launch_bf16<256, 160, 64, 4, 2, 3, 1>(p, st) : launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
+    case 256128064: return pingpong() ? launch_bf16<256, 128, 64, 4, 2, 3, 1>(p, st) : launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
     default: break;
   }
   set_error("ldm_conv_gemm: no kernel for tile %dx%dx%d", bm, bn, bk);

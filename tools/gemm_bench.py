@@ -59,7 +59,12 @@ def main():
         w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
         bias = torch.randn(N, device=dev, generator=g)
         kw = dict(a1=a1, ksize=ks, stride=stride, upsample=up, bias=bias, glu=glu)
-        for tile in tiles:
+        variants = [(t, None) for t in tiles]
+        if "--pp" in sys.argv:      # the plain ring against its ping-pong form (LDM_GEMM_PINGPONG), same process, same buffers
+            variants = [(t, pp) for t in tiles for pp in ("0", "1")]
+        for tile, pp in variants:
+            if pp is not None:
+                os.environ["LDM_GEMM_PINGPONG"] = pp
             if tile is None:
                 os.environ.pop("LDM_GEMM_TILE", None)
             elif glu and tile.split(",")[1] == "160":
@@ -78,7 +83,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
             fl = 2.0 * M * N * K
-            print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d} tile={tile or 'auto':8s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s",
+            print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d} tile={tile or 'auto':8s}{' pp=' + pp if pp is not None else ''} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s",
                   flush=True)
         os.environ.pop("LDM_GEMM_TILE", None)
 
