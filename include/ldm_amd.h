@@ -200,6 +200,10 @@ typedef struct LdmConvGemm {
   const float* ln_colsum;      /* LDM_EPI_LNFOLD: [n] float32 */
   int32_t ln_segments;         /* LDM_EPI_LNFOLD: segments per row of ln_stats (= c0 / 80) */
   float ln_eps;                /* LDM_EPI_LNFOLD: LayerNorm eps (1e-5 in the reference) */
+  /* Training forward of the GLU feed-forward (ABI version 3; NULL when unused): with LDM_EPI_GEGLU / LDM_EPI_SWIGLU and bf16
+   * output, also store the biased pre-activation, [m][n] bf16 in the filter's paired column order (16 values, their 16
+   * gates, ...) -- the tensor autograd keeps for the backward of unet.py:787-790 -- so the forward needs no second pass. */
+  void* glu_preact;
 } LdmConvGemm;
 
 /* Dropout (unet.py:636-639, :707, :579: nn.Dropout(p) after the attention output projection, inside ResnetBlock.layers and the

@@ -41,6 +41,7 @@ struct ConvGemmParams {
   int ln_nseg;
   const float* ln_s1;     //   [N]: sum_k W'[n][k] of the gamma-scaled filter this call multiplies with
   float ln_eps;
+  void* glu_preact; // GLU epilogues, bf16: also store the biased pre-activation [M][N] (paired column order) -- the training forward
   int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
   float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
@@ -377,9 +378,11 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // part in the partial last B pass) per tile.
     static_assert(STAGES == 3, "ring depth");
     const bool extra = B_IT > B_FULL && (B_FULL * NT + wave * 64) < BN * CH;
-    stage(0, kt_begin);
-    if (nk > 1) stage(1, kt_begin + 1);
-    ln_finish();
+    if constexpr (PP != 2) {
+      stage(0, kt_begin);
+      if (nk > 1) stage(1, kt_begin + 1);
+      ln_finish();
+    }
     int slot = 0;
     if constexpr (PP) {
       // Ping-pong form of the ring: the waves of a workgroup are two groups of WM*WN/2, one wave of each per SIMD.  A
@@ -441,6 +444,95 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         if (LDM_ABLATE(1)) { stage_begin(buf, kt); return; }
         stage(buf, kt);
       };
+      // PP == 2: the per-tile staging arithmetic as straight-line code that runs UNDER the MFMAs of the M phase (the R phase
+      // then only issues instructions that move data).  Per lane and staged row: the byte offset of the row's input pixel at
+      // tap (0, 0) for each source, and one validity bit per tap; a tap is then a scalar byte shift and a bit test.
+      unsigned pb0[A_IT], pb1[A_IT], tapmask[A_IT];
+      if constexpr (PP == 2) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const int r = (it * NT + tid) / CH;
+          const int m = m0 + r;
+          int pix = 0;
+          unsigned mask = 0;
+          if (m < p.M && pointwise) {
+            pix = m;
+            mask = 1;
+          } else if (m < p.M) {
+            const int b = sample_of(m), rem = m - b * hw_out;
+            const int oh = ext_pow2 ? rem >> sh_w : rem / p.wout, ow = rem - oh * p.wout;
+            const int ih0 = oh * p.stride - pad, iw0 = ow * p.stride - pad;
+            pix = (b * p.hin + ih0) * p.win + iw0;
+            unsigned cols = 0;
+            for (int kw = 0; kw < p.ksize; ++kw) cols |= ((unsigned)(iw0 + kw) < (unsigned)p.win ? 1u : 0u) << kw;
+            for (int kh = 0; kh < p.ksize; ++kh)
+              if ((unsigned)(ih0 + kh) < (unsigned)p.hin) mask |= cols << (kh * p.ksize);
+          }
+          const unsigned sw = (unsigned)((cpos ^ swz<CH>(r)) * 8);
+          pb0[it] = ((unsigned)pix * (unsigned)p.c0 + sw) * 2u;
+          pb1[it] = ((unsigned)pix * (unsigned)p.c1 + sw) * 2u;
+          tapmask[it] = mask;
+        }
+      }
+      auto pp_prepare = [&](int buf, int kt) {
+        st_sa = smem + buf * STAGE;
+        const int t = it_tap;
+        const int kh = (t * 11) >> 5, kw = t - kh * p.ksize;      // t / 3 for t < 12 (ksize 1: t == 0)
+        const bool sec = it_second != 0;
+        const int cs = sec ? p.c1 : p.c0;
+        const unsigned shift = (unsigned)((kh * p.win + kw) * cs) * 2u;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+          const unsigned base = sec ? pb1[it] : pb0[it];
+          a_voff[it] = ((tapmask[it] >> t) & 1u) ? base + shift : OOB;
+        }
+        st_abase = sec ? p.a1 : p.a0;
+        st_abytes = sec ? bytes_a1 : bytes_a0;
+        st_soff_a = it_cc * 2;
+        st_soff_b = kt * (BK * 2);
+        const int cc = it_cc + BK;
+        const bool wrap = cc >= cs;
+        const bool to_second = wrap && !sec && p.c1 > 0;
+        // (kept on the scalar unit: without the readfirstlane the compiler turns the flag arithmetic into vector code and
+        // every use of the tap index with it)
+        it_tap = __builtin_amdgcn_readfirstlane(it_tap + ((wrap && !to_second) ? 1 : 0));
+        it_second = __builtin_amdgcn_readfirstlane(wrap ? (to_second ? 1 : 0) : it_second);
+        it_cc = __builtin_amdgcn_readfirstlane(wrap ? 0 : cc);
+      };
+      // Pins the results of pp_prepare where they are: the compiler otherwise sinks the whole computation to its use, the
+      // DMA issue of the next R phase -- the phase it was taken out of.
+      auto pp_pin = [&]() {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) asm volatile("" : "+v"(a_voff[it]));
+        asm volatile("" : "+s"(st_soff_a), "+s"(st_soff_b), "+s"(st_abytes), "+s"(it_tap), "+s"(it_cc), "+s"(it_second));
+      };
+      auto pp_issue = [&]() {
+        [&]<int... I>(std::integer_sequence<int, I...>) { stage_all(std::integral_constant<int, I>{}...); }
+        (std::make_integer_sequence<int, NPIECE>{});
+      };
+      // M phase of PP == 2: the staging arithmetic of the tile three ahead, then the MFMAs, in ONE basic block; the
+      // scheduling groups below make the compiler place two scalar / one vector instruction of it behind every MFMA.
+      auto mfma_and_prepare = [&](int buf, int kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        pp_prepare(buf, kt);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks][i], bfr[ks][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < KS * MI * NI; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);   // two SALU
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);   // one VALU
+        }
+        pp_pin();
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
       // all of this wave's LDS-DMA has landed except the batch issued last (when one more tile was staged)
       auto wait_older_dma = [&](bool newer_in_flight) {
         if (LDM_ABLATE(9)) return;
@@ -457,6 +549,14 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       };
+      if constexpr (PP == 2) {
+        pp_prepare(0, kt_begin);
+        pp_issue();
+        if (nk > 1) { pp_prepare(1, kt_begin + 1); pp_issue(); }
+        ln_finish();
+        pp_prepare(2, kt_begin + 2);          // the state R(0) issues from (never issued when nk < 3)
+        pp_pin();
+      }
       wait_older_dma(nk > 1);                 // tile 0 (tile 1 may still be in flight)
       barrier();
       if (wave < WM * WN / 2) {
@@ -464,12 +564,14 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           if (kt == 8) LDM_STAMP(8);
           read_frags(slot);
           const bool more = kt + 2 < nk;
-          if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+          if constexpr (PP == 2) { if (more) pp_issue(); }
+          else { if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2); }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (kt == 8) LDM_STAMP(9);
           barrier();
           if (kt == 8) LDM_STAMP(10);
-          mfma_all();
+          if constexpr (PP == 2) mfma_and_prepare(slot, kt_begin + kt + 3);
+          else mfma_all();
           wait_older_dma(more);
           if (kt == 8) LDM_STAMP(11);
           barrier();
@@ -477,11 +579,15 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         }
       } else {
         for (int kt = 0; kt < nk; ++kt) {
-          if (kt > 0) mfma_all();
+          if (kt > 0) {
+            if constexpr (PP == 2) mfma_and_prepare(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+            else mfma_all();
+          }
           barrier();
           read_frags(slot);
           const bool more = kt + 2 < nk;
-          if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+          if constexpr (PP == 2) { if (more) pp_issue(); }
+          else { if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2); }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           wait_older_dma(more);
           barrier();
@@ -539,8 +645,9 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // The chunk geometry is compile-time, the bias is loaded once per lane, and the residual / time-embedding
     // operands of 16-row step i+1 are requested before step i is transposed, so their L2 latency (the bulk of the
     // epilogue when it was paid 3x per step) hides behind the LDS round trip and the stores of the step before.
-    auto run = [&](auto glu_tag) {
+    auto run = [&](auto glu_tag, auto preact_tag) {
       constexpr bool GLU = decltype(glu_tag)::value;
+      constexpr bool PREACT = decltype(preact_tag)::value;   // compile-time: as a run-time branch inside the unrolled steps it cost the inference GLU launches 11 %
       constexpr int LDC = WTN + 4;                                // floats per staged row (+4: spreads the 4 row groups)
       static_assert(WM * WN * 16 * LDC * 4 <= STAGES * STAGE, "epilogue staging does not fit the tile buffers");
       constexpr int CPRW = GLU ? WTN / 16 : WTN / 8;              // 8-column output chunks per staged row
@@ -651,6 +758,11 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) g[e] += bg[ps][e];
             }
+            if constexpr (PREACT) {   // what the backward differentiates: value and gate blocks as the plain GEMM lays them out
+              bf16_t* pa = static_cast<bf16_t*>(p.glu_preact) + (size_t)m * p.N + ncol[ps];
+              store8(pa, v);
+              store8(pa + 16, g);
+            }
             if (epi & LDM_EPI_GEGLU) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_fast(g[e]);
@@ -707,9 +819,12 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       }
     };
     if (glu) {
-      if constexpr (NI % 2 == 0) run(std::true_type{});
+      if constexpr (NI % 2 == 0) {
+        if (p.glu_preact != nullptr) run(std::true_type{}, std::true_type{});
+        else run(std::true_type{}, std::false_type{});
+      }
     } else {
-      run(std::false_type{});
+      run(std::false_type{}, std::false_type{});
     }
     LDM_STAMP(4);
     LDM_STAMP(6);
@@ -969,10 +1084,14 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
   return LDM_OK;
 }
 
-// LDM_GEMM_PINGPONG=0/1: the plain ring or its ping-pong form for the 256-row tiles (read per call: A/B runs in one process)
-static bool pingpong() {
+// Which form of the 3-slot ring the 256-row tiles run: 2 = ping-pong with the staging arithmetic under the MFMAs (default),
+// 1 = ping-pong with the ring's own staging code (the layers form 2 does not cover: folded upsampling), 0 = the plain ring.
+// LDM_GEMM_PINGPONG overrides (read per call: A/B runs in one process, tools/gemm_bench.py --pp).
+static int pingpong(const ConvGemmParams& p) {
   const char* e = getenv("LDM_GEMM_PINGPONG");
-  return e ? atoi(e) != 0 : false;
+  const int v = e ? atoi(e) : 2;
+  if (v == 2 && p.upsample) return 1;   // form 2 keeps one tap shift per K-tile: not linear under the folded upsample
+  return v;
 }
 
 // Expected efficiency of a (tile, split-K) choice: padding waste x chip fill x operand reuse x split-K overhead.
@@ -1092,6 +1211,7 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.ln_nseg = d->ln_segments;
   p.ln_s1 = d->ln_colsum;
   p.ln_eps = d->ln_eps;
+  p.glu_preact = d->glu_preact;
 #ifdef LDM_GEMM_STAMPS
   p.stamps = nullptr;
   {
@@ -1117,6 +1237,7 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   }
 
   if (d->dtype == LDM_F32) {
+    LDM_REQUIRE(d->glu_preact == nullptr, "ldm_conv_gemm: glu_preact is bf16-only");
     LDM_REQUIRE(p.ctot % 16 == 0 && p.c0 % 16 == 0, "ldm_conv_gemm(f32): channel counts must be multiples of 16 (c0=%d c1=%d)", d->c0, d->c1);
     LDM_REQUIRE(aligned16(d->a0) && aligned16(p.a1) && aligned16(d->w), "ldm_conv_gemm: operands must be 16-byte aligned");
     p.tiles_m = (p.M + 63) / 64;
@@ -1144,6 +1265,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     if (glu) ok = ok && p.N % 32 == 0;
     p.vec_epilogue = ok ? 1 : 0;
   }
+  LDM_REQUIRE(d->glu_preact == nullptr || (glu && p.vec_epilogue && d->out_dtype == LDM_BF16 && aligned16(d->glu_preact)),
+              "ldm_conv_gemm: glu_preact needs a GLU epilogue, bf16 output, 16-byte aligned operands and n %% 32 == 0");
   LDM_REQUIRE(p.vec_epilogue || !(epi & (LDM_EPI_ROWSTATS | LDM_EPI_LNFOLD)),
               "ldm_conv_gemm: LDM_EPI_ROWSTATS / LDM_EPI_LNFOLD need 16-byte aligned operands and n %% 8 == 0");
   int bm, bn, bk;
@@ -1163,8 +1286,18 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
     case 64128064: return launch_bf16<64, 128, 64, 2, 2>(p, st);
     case 128160064: return launch_bf16<128, 160, 64, 2, 2>(p, st);
     case 64160064: return launch_bf16<64, 160, 64, 2, 2>(p, st);
-    case 256160064: return pingpong() ? launch_bf16<256, 160, 64, 4, 2, 3, 1>(p, st) : launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
-    case 256128064: return pingpong() ? launch_bf16<256, 128, 64, 4, 2, 3, 1>(p, st) : launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
+    case 256160064:
+      switch (pingpong(p)) {
+        case 1: return launch_bf16<256, 160, 64, 4, 2, 3, 1>(p, st);
+        case 2: return launch_bf16<256, 160, 64, 4, 2, 3, 2>(p, st);
+        default: return launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
+      }
+    case 256128064:
+      switch (pingpong(p)) {
+        case 1: return launch_bf16<256, 128, 64, 4, 2, 3, 1>(p, st);
+        case 2: return launch_bf16<256, 128, 64, 4, 2, 3, 2>(p, st);
+        default: return launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
+      }
     default: break;
   }
   set_error("ldm_conv_gemm: no kernel for tile %dx%dx%d", bm, bn, bk);

@@ -49,6 +49,7 @@ class ConvGemmDesc(C.Structure):
         ("workspace", c_void_p), ("workspace_bytes", C.c_int64),
         ("rowstats", c_void_p), ("ln_stats", c_void_p), ("ln_colsum", c_void_p),
         ("ln_segments", C.c_int32), ("ln_eps", C.c_float),
+        ("glu_preact", c_void_p),
     ]
 
 

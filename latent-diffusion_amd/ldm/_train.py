@@ -18,6 +18,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, List, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -75,6 +77,9 @@ class Tape:
         self.dctx = g if self.dctx is None else ops.add(self.dctx, g)
 
 
+_GLU_FUSED = os.environ.get("LDM_TRAIN_GLU_FUSED", "1") != "0"      # A/B switch (tools/): 0 = plain GEMM + glu_forward pass
+
+
 def glu_rows_to_checkpoint(g: torch.Tensor) -> torch.Tensor:
     """Rows in ldm_pack_weight(glu_pairs) order (blocks of 16 values then their 16 gates) -> [values | gates].
     Returns a strided view whose element order is the checkpoint's: whoever stores it (Tape.put -> the gradient bucket,
@@ -90,12 +95,15 @@ def glu_rows_to_packed(w: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------ layers
 def conv_train(T: Tape, name: str, a0, *, a1=None, ksize=1, stride=1, upsample=False, rowvec=None, residual=None,
-               has_bias=True, grad_map=None):
+               has_bias=True, grad_map=None, glu=None):
     """ops.conv_gemm + backward closure.  bwd(dy, need_dx=True, add=None) -> dx over all c0+c1 channels (+ add).
-    The gradient of ``residual`` is dy itself; the gradient of ``rowvec`` is colsum(dy, segments=B) (callers do both)."""
+    The gradient of ``residual`` is dy itself; the gradient of ``rowvec`` is colsum(dy, segments=B) (callers do both).
+    ``glu`` ("geglu" / "swiglu", bf16): the GEMM's epilogue applies the gated activation and ALSO stores the pre-activation;
+    returns ((gated, pre), bwd) where bwd takes the gradient of ``pre``."""
     P = T.P
     out = ops.conv_gemm(a0, P[name + ".w"], a1=a1, ksize=ksize, stride=stride, upsample=upsample,
-                        bias=P[name + ".b"] if has_bias else None, rowvec=rowvec, residual=residual)
+                        bias=P[name + ".b"] if has_bias else None, rowvec=rowvec, residual=residual,
+                        glu=glu, glu_preact=glu is not None)
     in_hw = (a0.shape[1], a0.shape[2]) if a0.dim() == 4 else None
 
     def bwd(dy, need_dx=True, add=None, bias_from=None):
@@ -201,9 +209,13 @@ def transformer_block_train(T: Tape, n: str, blk, x, ctx):
     y2 = ln("norm2", x1)
     x2, a2_bwd = attention_train(T, _j(n, "attn2"), blk.attn2, y2, ctx, residual=x1)
     y3 = ln("feed_forward.0", x2)
-    hpre, h_bwd = conv_train(T, _j(n, "feed_forward.1.w1_w2"), y3,          # packed (value|gate interleaved) columns
-                             grad_map=glu_rows_to_checkpoint)
-    gl = ops.glu_forward(hpre, blk.activation_fn)
+    if y3.dtype == torch.bfloat16 and _GLU_FUSED:      # one launch: the GEMM's GLU epilogue also stores the pre-activation the backward needs
+        (gl, hpre), h_bwd = conv_train(T, _j(n, "feed_forward.1.w1_w2"), y3, grad_map=glu_rows_to_checkpoint,
+                                       glu=blk.activation_fn)
+    else:
+        hpre, h_bwd = conv_train(T, _j(n, "feed_forward.1.w1_w2"), y3,      # packed (value|gate interleaved) columns
+                                 grad_map=glu_rows_to_checkpoint)
+        gl = ops.glu_forward(hpre, blk.activation_fn)
     out, o_bwd = conv_train(T, _j(n, "feed_forward.3"), gl)                 # no residual round the FF (:595)
 
     def bwd(dout):

@@ -191,14 +191,17 @@ class PackPlan:
 def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] = None, ksize: int = 1, stride: int = 1,
               upsample: bool = False, bias: Optional[torch.Tensor] = None, rowvec: Optional[torch.Tensor] = None,
               residual: Optional[torch.Tensor] = None, silu: bool = False, glu: Optional[str] = None,
-              out_dtype: Optional[torch.dtype] = None, out_hw=None, rowstats: bool = False, ln=None):
+              out_dtype: Optional[torch.dtype] = None, out_hw=None, rowstats: bool = False, ln=None,
+              glu_preact: bool = False):
     """Implicit-GEMM conv / linear.  a0 (and a1): (B, H, W, C) NHWC, or (..., C) matrices for ksize == 1.
     w: packed [N, ksize*ksize*(C0+C1)].  Returns NHWC (B, Hout, Wout, N') / (..., N').
     upsample: False, True (nearest 2x, unet.py:316) or "zero" (zero-insertion 2x: input gradient of a stride-2 conv).
     LayerNorm fold (bf16; include/ldm_amd.h LDM_EPI_ROWSTATS / LDM_EPI_LNFOLD): ``rowstats=True`` returns (out, stats) with
     stats (M, N / 80, 2) float32 = per-row partial (sum, sumsq) of the output; ``ln=(stats, colsum, eps)`` treats a0 as the
     INPUT of a LayerNorm whose statistics are ``stats``: w must be the gamma-scaled filter, colsum its row sums, and bias
-    must already contain W beta (``fold_layernorm`` builds the three)."""
+    must already contain W beta (``fold_layernorm`` builds the three).
+    ``glu_preact=True`` (GLU epilogues, bf16): returns (out, pre) with pre (..., N) the biased pre-activation in the filter's
+    paired column order -- what the training forward keeps for ``glu_backward``."""
     _gpu(a0, a1, w, bias, rowvec, residual)
     if not a0.is_contiguous() or (a1 is not None and not a1.is_contiguous()):
         raise ValueError("conv_gemm: activations must be contiguous NHWC")
@@ -262,6 +265,12 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
                      ksize=ksize, stride=stride, upsample=(2 if upsample == "zero" else 1 if upsample else 0), w=w.data_ptr(), n=n, epilogue=epi,
                      bias=_ptr(bias), rowvec=_ptr(rowvec), rowvec_stride=0 if rowvec is None else rowvec.stride(0),
                      residual=_ptr(residual), out=out.data_ptr(), dtype=dt_code(a0.dtype), out_dtype=dt_code(odt))
+    pre = None
+    if glu_preact:
+        if not glu or a0.dtype != torch.bfloat16 or odt != torch.bfloat16 or n % 32:
+            raise ValueError("conv_gemm(glu_preact=True): GLU epilogue, bf16 in and out, N a multiple of 32")
+        pre = torch.empty((*out_lead, n), dtype=odt, device=a0.device)
+        d.glu_preact = pre.data_ptr()
     stats = None
     if rowstats:
         if n % 160 or (c0 + c1) % 64 or c0 % 64 or a0.dtype != torch.bfloat16 or glu or odt != torch.bfloat16:
@@ -298,6 +307,8 @@ def conv_gemm(a0: torch.Tensor, w: torch.Tensor, *, a1: Optional[torch.Tensor] =
             _launch_log.append((f"conv_gemm_{'bf16' if a0.dtype == torch.bfloat16 else 'f32'}_kernel<{tile[0]},{tile[1]},{tile[2]}>",
                                 2.0 * m * n * ksize * ksize * (c0 + c1), e0, e1,
                                 (m, n, ksize * ksize * (c0 + c1), ksize, stride, int(bool(upsample)), c1, epi)))
+    if glu_preact:
+        return out, pre
     return (out, stats) if rowstats else out
 
 

@@ -212,6 +212,7 @@ static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int)
 #define __builtin_amdgcn_wave_barrier ::emu::wave_barrier
 #define __builtin_amdgcn_s_barrier ::emu::barrier
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_memtime ::emu::clock_ticks
 #define __builtin_amdgcn_s_sleep(n) ((void)0)

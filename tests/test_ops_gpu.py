@@ -201,6 +201,33 @@ def test_every_bf16_tile(tile, monkeypatch):
     assert list(t) == [bm, bn, 64], list(t)
 
 
+@pytest.mark.parametrize("act", ["geglu", "swiglu"])
+@pytest.mark.parametrize("tile", [None, "64,128", "256,128"])
+def test_glu_epilogue_keeps_the_preactivation(act, tile, monkeypatch):
+    """Training forward of the feed-forward: the GLU epilogue also stores the biased pre-activation (glu_preact).  It must be
+    bit-equal to what the plain GEMM writes (same accumulation, same rounding), and the gated output must equal the
+    inference epilogue's (the same launch without the second store)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    if tile:
+        monkeypatch.setenv("LDM_GEMM_TILE", tile)
+    x, xr = _q(seeded((1000, 320), 1), dtype)
+    w = seeded((512, 320), 2) / math.sqrt(320)
+    b = seeded((512,), 3)
+    wp = ops.pack_weight(w.cuda(), dtype, glu_pairs=True)
+    bp = ops.pack_weight(b.cuda(), torch.float32, glu_pairs=True).flatten()
+    out, pre = ops.conv_gemm(x, wp, bias=bp, glu=act, glu_preact=True)
+    assert out.shape == (1000, 256) and pre.shape == (1000, 512) and pre.dtype == dtype
+    assert torch.equal(pre, ops.conv_gemm(x, wp, bias=bp))
+    assert torch.equal(out, ops.conv_gemm(x, wp, bias=bp, glu=act))
+    val, gate = F.linear(xr, w.to(dtype).float(), b).chunk(2, dim=-1)
+    ref = val * (F.gelu(gate) if act == "geglu" else F.silu(gate))
+    assert rel_l2(out, ref) < TOL[dtype]
+    assert rel_l2(ops.glu_forward(pre, act), ref) < 2 * TOL[dtype]
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, wp, bias=bp, glu_preact=True)                      # no GLU epilogue
+
+
 @pytest.mark.parametrize("tile", [None, "64,128,2", "128,128,3", "128,160,4", "256,128,2", "64,160,8"])
 def test_split_k(tile, monkeypatch):
     """Small-M layers (the 8x8 level) split K over blockIdx.y into a lent workspace and fold deterministically:

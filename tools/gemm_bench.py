@@ -58,10 +58,15 @@ def main():
         K = ks * ks * (c0 + c1)
         w = (torch.randn(N, K, device=dev, generator=g) / math.sqrt(K)).bfloat16()
         bias = torch.randn(N, device=dev, generator=g)
+        if "--ones" in sys.argv:    # constant operands: the matrix cores toggle almost no bits -> what the schedule is worth without the power limit
+            a0.fill_(1.0)
+            w.fill_(1.0 / K)
+            if a1 is not None:
+                a1.fill_(1.0)
         kw = dict(a1=a1, ksize=ks, stride=stride, upsample=up, bias=bias, glu=glu)
         variants = [(t, None) for t in tiles]
         if "--pp" in sys.argv:      # the plain ring against its ping-pong form (LDM_GEMM_PINGPONG), same process, same buffers
-            variants = [(t, pp) for t in tiles for pp in ("0", "1")]
+            variants = [(t, pp) for t in tiles for pp in ("0", "2")]
         for tile, pp in variants:
             if pp is not None:
                 os.environ["LDM_GEMM_PINGPONG"] = pp
@@ -82,6 +87,18 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / iters
+            if "--gap" in sys.argv:  # single launches after an idle gap (the clock has recovered): median of 7
+                import time
+                one = []
+                for _ in range(7):
+                    torch.cuda.synchronize()
+                    time.sleep(0.03)
+                    e0.record()
+                    ops.conv_gemm(a0, w, **kw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    one.append(e0.elapsed_time(e1) * 1e3)
+                us = sorted(one)[3]
             fl = 2.0 * M * N * K
             print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d} tile={tile or 'auto':8s}{' pp=' + pp if pp is not None else ''} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s",
                   flush=True)
