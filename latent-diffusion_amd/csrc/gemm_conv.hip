@@ -378,7 +378,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     // part in the partial last B pass) per tile.
     static_assert(STAGES == 3, "ring depth");
     const bool extra = B_IT > B_FULL && (B_FULL * NT + wave * 64) < BN * CH;
-    if constexpr (PP != 2) {
+    if constexpr (PP < 2) {
       stage(0, kt_begin);
       if (nk > 1) stage(1, kt_begin + 1);
       ln_finish();
@@ -448,7 +448,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       // then only issues instructions that move data).  Per lane and staged row: the byte offset of the row's input pixel at
       // tap (0, 0) for each source, and one validity bit per tap; a tap is then a scalar byte shift and a bit test.
       unsigned pb0[A_IT], pb1[A_IT], tapmask[A_IT];
-      if constexpr (PP == 2) {
+      if constexpr (PP >= 2) {
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
           const int r = (it * NT + tid) / CH;
@@ -512,6 +512,8 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       };
       // M phase of PP == 2: the staging arithmetic of the tile three ahead, then the MFMAs, in ONE basic block; the
       // scheduling groups below make the compiler place two scalar / one vector instruction of it behind every MFMA.
+      // (Measured and dropped: issuing the last four MFMAs of an M phase after the barrier that ends it, so that the wave
+      // reaches the barrier earlier -- +2.6 % on one shape, -1.4 % on others, whole step 31.89 against 31.76 ms.)
       auto mfma_and_prepare = [&](int buf, int kt) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -549,7 +551,7 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
       };
-      if constexpr (PP == 2) {
+      if constexpr (PP >= 2) {
         pp_prepare(0, kt_begin);
         pp_issue();
         if (nk > 1) { pp_prepare(1, kt_begin + 1); pp_issue(); }
@@ -564,13 +566,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           if (kt == 8) LDM_STAMP(8);
           read_frags(slot);
           const bool more = kt + 2 < nk;
-          if constexpr (PP == 2) { if (more) pp_issue(); }
+          if constexpr (PP >= 2) { if (more) pp_issue(); }
           else { if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2); }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (kt == 8) LDM_STAMP(9);
           barrier();
           if (kt == 8) LDM_STAMP(10);
-          if constexpr (PP == 2) mfma_and_prepare(slot, kt_begin + kt + 3);
+          if constexpr (PP >= 2) mfma_and_prepare(slot, kt_begin + kt + 3);
           else mfma_all();
           wait_older_dma(more);
           if (kt == 8) LDM_STAMP(11);
@@ -580,13 +582,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       } else {
         for (int kt = 0; kt < nk; ++kt) {
           if (kt > 0) {
-            if constexpr (PP == 2) mfma_and_prepare(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
+            if constexpr (PP >= 2) mfma_and_prepare(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
             else mfma_all();
           }
           barrier();
           read_frags(slot);
           const bool more = kt + 2 < nk;
-          if constexpr (PP == 2) { if (more) pp_issue(); }
+          if constexpr (PP >= 2) { if (more) pp_issue(); }
           else { if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2); }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           wait_older_dma(more);
@@ -1089,8 +1091,8 @@ static int launch_bf16(ConvGemmParams& p, hipStream_t st) {
 // LDM_GEMM_PINGPONG overrides (read per call: A/B runs in one process, tools/gemm_bench.py --pp).
 static int pingpong(const ConvGemmParams& p) {
   const char* e = getenv("LDM_GEMM_PINGPONG");
-  const int v = e ? atoi(e) : 2;
-  if (v == 2 && p.upsample) return 1;   // form 2 keeps one tap shift per K-tile: not linear under the folded upsample
+  const int v = e ? (atoi(e) > 2 ? 2 : atoi(e)) : 2;
+  if (v >= 2 && p.upsample) return 1;   // form 2 keeps one tap shift per K-tile: not linear under the folded upsample
   return v;
 }
 
@@ -1292,12 +1294,8 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
         case 2: return launch_bf16<256, 160, 64, 4, 2, 3, 2>(p, st);
         default: return launch_bf16<256, 160, 64, 4, 2, 3>(p, st);
       }
-    case 256128064:
-      switch (pingpong(p)) {
-        case 1: return launch_bf16<256, 128, 64, 4, 2, 3, 1>(p, st);
-        case 2: return launch_bf16<256, 128, 64, 4, 2, 3, 2>(p, st);
-        default: return launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
-      }
+    case 256128064:   // (GLU layers and forced tiles: form 1 is not instantiated for it)
+      return pingpong(p) == 2 ? launch_bf16<256, 128, 64, 4, 2, 3, 2>(p, st) : launch_bf16<256, 128, 64, 4, 2, 3>(p, st);
     default: break;
   }
   set_error("ldm_conv_gemm: no kernel for tile %dx%dx%d", bm, bn, bk);

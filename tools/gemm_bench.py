@@ -26,6 +26,11 @@ CASES = [  # name, (H, W, C0, C1), N, ksize, stride, up, glu
     ("L0 proj 320->320", (64, 64, 320, 0), 320, 1, 1, False, None),
     ("L1 geglu 640->5120", (32, 32, 640, 0), 5120, 1, 1, False, "geglu"),
     ("L2 geglu 1280->10240", (16, 16, 1280, 0), 10240, 1, 1, False, "geglu"),
+    # the same GEMMs with the cheaper gate (exp + rcp + 2 instead of the erf's ~17 + two quarter-rate): what the epilogue's
+    # vector arithmetic costs the GLU launches
+    ("L0 swiglu 320->2560", (64, 64, 320, 0), 2560, 1, 1, False, "swiglu"),
+    ("L1 swiglu 640->5120", (32, 32, 640, 0), 5120, 1, 1, False, "swiglu"),
+    ("L2 swiglu 1280->10240", (16, 16, 1280, 0), 10240, 1, 1, False, "swiglu"),
     ("ctx kv 768->640", (77, 1, 768, 0), 640, 1, 1, False, None),
     # the GLU projections' shapes WITHOUT the gate epilogue: what the tile alone is worth on them
     ("L0 ff1 plain 320->2560", (64, 64, 320, 0), 2560, 1, 1, False, None),
