@@ -82,9 +82,15 @@ def main():
         import json
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         from bench import kernel_source_hash
+        # instantiations of one tile (the ring forms of the 256-row GEMM tiles differ in their last template argument) are
+        # one kernel to bench.py, which names a GEMM by its tile: bytes and launches are summed over them
+        agg = defaultdict(lambda: [0.0, 0])
+        for t, k, n, util, wany, winst, act, clk, rd, wb, bw in rows:
+            agg[full_name(k)][0] += rd + wb
+            agg[full_name(k)][1] += n
         rec = {"source_hash": kernel_source_hash(), "profile": profile,
-               "workloads": {workload: {full_name(k): {"hbm_bytes_per_launch": (rd + wb) / n, "launches_per_forward": n / fwd}
-                                        for t, k, n, util, wany, winst, act, clk, rd, wb, bw in rows if n}}}
+               "workloads": {workload: {k: {"hbm_bytes_per_launch": b / n, "launches_per_forward": n / fwd}
+                                        for k, (b, n) in agg.items() if n}}}
         with open(json_out, "w") as f:
             json.dump(rec, f, indent=1, sort_keys=True)
 
