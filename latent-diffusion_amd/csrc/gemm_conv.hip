@@ -385,17 +385,19 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
     }
     int slot = 0;
     if constexpr (PP) {
-      // Ping-pong form of the ring: the waves of a workgroup are two groups of WM*WN/2, one wave of each per SIMD.  A
-      // K-tile is two phases; in each, one group only issues its MFMAs (all fragments of the K-tile already in registers)
-      // while the other reads its fragments of the next tile from LDS and issues its share of the LDS-DMA of the tile
-      // after next; a workgroup barrier swaps the roles.  The matrix cores of a SIMD then always have one wave that does
-      // nothing but feed them, and the barrier wait / staging arithmetic / fragment reads of the other wave run under it
-      // (in the plain ring both waves of a SIMD reach the barrier and the staging code together: per K-tile ~2,200 cycles
-      // for 1,280 of matrix-core time).
-      //   group 0:  R(kt)   | M(kt)   | R(kt+1) | M(kt+1) ...        R = fragment reads + DMA issue, M = MFMAs
-      //   group 1:  M(kt-1) | R(kt)   | M(kt)   | R(kt+1) ...
-      // Tile kt is read in phases 2kt (group 0) and 2kt+1 (group 1); its slot is refilled with tile kt+3 from phase
-      // 2kt+2 on; every wave waits for its own DMA of tile kt+1 before the barrier that ends phase 2kt+1.
+      // Ping-pong form of the ring: the waves of a workgroup are two groups of WM*WN/2, one wave of each per SIMD, that run
+      // the same two phases per K-tile in opposite order:
+      //   R = read all fragments of the K-tile from LDS into registers + issue this wave's share of the LDS-DMA of the tile
+      //       after next;   M = the K-tile's MFMAs, nothing else in the way (PP == 2: the next staging arithmetic under them)
+      //   group 0:  | R(kt)   M(kt)   | R(kt+1) M(kt+1) | ...          '|' = the ONE workgroup barrier per K-tile
+      //   group 1:  | M(kt-1) R(kt)   | M(kt)   R(kt+1) | ...
+      // so the matrix cores of a SIMD always have one wave that only feeds them while the other waits on LDS and on the
+      // DMA issue path (in the plain ring both waves of a SIMD reach the barrier and the staging code together: ~2,200
+      // cycles per K-tile for 1,280 of matrix-core time).  What the barrier in front of K-tile kt guarantees: every wave's DMA
+      // of tile kt has landed (each waited for its own before it), and every wave has finished reading tile kt-1 (group 1's
+      // R(kt-1) is the second half of the interval before it), whose slot the tile kt+2 issued after the barrier refills.
+      // A first version had a second barrier between the two phases (phase = max(R, M) + barrier); without it an interval
+      // is R + M + barrier: -3..7 % per launch on the 3x3 convolutions (profiles/r3_gemm_pingpong_one_barrier.txt).
       static_assert((WM * WN) % 2 == 0, "two wave groups");
       bf16x8_t af[KS][MI], bfr[KS][NI];
 #ifdef LDM_GEMM_STAMPS
@@ -568,9 +570,10 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
           const bool more = kt + 2 < nk;
           if constexpr (PP >= 2) { if (more) pp_issue(); }
           else { if (more) pp_stage(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2); }
+          // (kept although no barrier follows: with the compiler's counted waits alone -- MFMAs starting as their fragments
+          // arrive -- the step measured 0.1 ms slower)
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           if (kt == 8) LDM_STAMP(9);
-          barrier();
           if (kt == 8) LDM_STAMP(10);
           if constexpr (PP >= 2) mfma_and_prepare(slot, kt_begin + kt + 3);
           else mfma_all();
@@ -585,7 +588,6 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             if constexpr (PP >= 2) mfma_and_prepare(slot == 0 ? 2 : slot - 1, kt_begin + kt + 2);
             else mfma_all();
           }
-          barrier();
           read_frags(slot);
           const bool more = kt + 2 < nk;
           if constexpr (PP >= 2) { if (more) pp_issue(); }
