@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define LDM_ABI_VERSION 2   /* 2: struct LdmConvGemm gained the LayerNorm-fold fields at its end */
+#define LDM_ABI_VERSION 3   /* 2: struct LdmConvGemm gained the LayerNorm-fold fields at its end; 3: glu_preact behind them */
 
 enum { LDM_F32 = 0, LDM_BF16 = 1 };
 

@@ -18,7 +18,7 @@ import torch  # noqa: F401
 F32, BF16 = 0, 1
 
 EPI_BIAS, EPI_ROWVEC, EPI_RESIDUAL, EPI_SILU, EPI_GEGLU, EPI_SWIGLU, EPI_ROWSTATS, EPI_LNFOLD = 1, 2, 4, 8, 16, 32, 64, 128
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # LDM_AMD_LIB overrides the path (A/B runs of two builds of the library; there is still no fallback).
 _LIB_PATH = os.environ.get("LDM_AMD_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),

@@ -21,7 +21,7 @@ def test_library_exports_header_symbols():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/ldm_amd.h but not exported"
     assert declared == set(_lib.EXPORTED_SYMBOLS)
-    assert lib.ldm_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.ldm_abi_version() == _lib.ABI_VERSION == 3
 
 
 @pytest.mark.parametrize("sched", ["linear", "cosine", "sigmoid"])

@@ -201,6 +201,40 @@ def test_every_bf16_tile(tile, monkeypatch):
     assert list(t) == [bm, bn, 64], list(t)
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+def test_ring_forms_of_the_256_row_tiles_agree_bit_for_bit(form, monkeypatch):
+    """The 256-row tiles run their 3-slot ring as a ping-pong of two wave groups (default; form 1 = the variant the folded
+    upsample uses); LDM_GEMM_PINGPONG=0 is the plain ring.  Same accumulation order per output element -> identical bits:
+    3x3 conv with two sources + time embedding + ragged M, stride 2, nearest upsample, 1x1 with residual, short K."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    monkeypatch.setenv("LDM_GEMM_TILE", "256,160")
+    B, c0, c1, H, W, Cout = 9, 64, 64, 31, 30, 160
+    a, _ = _q(nhwc(seeded((B, c0, H, W), 7)), dtype)
+    s2, _ = _q(nhwc(seeded((B, c1, H, W), 8)), dtype)
+    wc = ops.pack_weight((seeded((Cout, c0 + c1, 3, 3), 9) / math.sqrt(9 * (c0 + c1))).cuda(), dtype)
+    bc = seeded((Cout,), 10).cuda()
+    rv, _ = _q(seeded((B, Cout), 11), dtype)
+    xx, _ = _q(nhwc(seeded((8, 64, 64, 64), 12)), dtype)
+    w3 = ops.pack_weight((seeded((160, 64, 3, 3), 13) / math.sqrt(9 * 64)).cuda(), dtype)
+    x, _ = _q(seeded((8200, 640), 1), dtype)
+    wl = ops.pack_weight((seeded((320, 640), 2) / math.sqrt(640)).cuda(), dtype)
+    res, _ = _q(seeded((8200, 320), 4), dtype)
+    xs, _ = _q(seeded((700, 64), 5), dtype)
+    wsh = ops.pack_weight(seeded((160, 64), 6).cuda(), dtype)
+
+    def run():
+        return [ops.conv_gemm(a, wc, a1=s2, ksize=3, bias=bc, rowvec=rv),
+                ops.conv_gemm(xx, w3, ksize=3, stride=2, bias=bc),
+                ops.conv_gemm(xx, w3, ksize=3, upsample=True, bias=bc),
+                ops.conv_gemm(x, wl, residual=res),
+                ops.conv_gemm(xs, wsh)]                                   # one K-tile
+    ref = run()
+    monkeypatch.setenv("LDM_GEMM_PINGPONG", form)
+    for got, want in zip(run(), ref):
+        assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("act", ["geglu", "swiglu"])
 @pytest.mark.parametrize("tile", [None, "64,128", "256,128"])
 def test_glu_epilogue_keeps_the_preactivation(act, tile, monkeypatch):
