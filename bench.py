@@ -157,6 +157,14 @@ def hbm_kernel_rows(dev, sched, ops, iters=24, warm=3):
         for f in fns[:warm]:
             f()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # These launches last 10-50 us, about what the host needs to issue one through Python: behind a ~2 ms spin kernel the
+        # host runs ahead, the queue is full when the first event fires, and the launches run back to back (what is timed
+        # is the GPU, not the issue rate of this loop).
+        torch.cuda.synchronize(dev)
+        try:
+            torch.cuda._sleep(4_000_000)
+        except Exception:
+            pass
         e0.record()
         for i in range(iters):
             fns[i % len(fns)]()

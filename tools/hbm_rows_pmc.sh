@@ -23,7 +23,7 @@ def load(path, ctr):
 fe = load(f"{out}/fetch_counter_collection.csv", "FETCH_SIZE")
 wr = load(f"{out}/write_counter_collection.csv", "WRITE_SIZE")
 rows = [json.loads(l) for l in open(f"{out}/rows.jsonl") if l.startswith("{")]
-want = {"ddpm_step_kernel": rows[0], "ddpm_add_noise_kernel": rows[1], "gn_fused_kernel": rows[2], "layernorm_kernel": rows[3]}
+want = {"ddpm_step": rows[0], "ddpm_add_noise": rows[1], "gn_fused_kernel": rows[2], "layernorm_kernel": rows[3]}
 print("| kernel (as launched by bench.py's hbm_kernels rows) | launches counted | FETCH_SIZE x 2 (gfx950) MB / launch | WRITE_SIZE MB / launch | "
       "algorithmic MB / launch | counted / algorithmic | us / launch (un-profiled) | algorithmic GB/s |")
 print("|---|---|---|---|---|---|---|---|")
