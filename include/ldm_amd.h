@@ -208,7 +208,8 @@ typedef struct LdmConvGemm {
 
 /* Dropout (unet.py:636-639, :707, :579: nn.Dropout(p) after the attention output projection, inside ResnetBlock.layers and the
  * feed-forward) has no kernel here: the reference's trainer and every default leave p = 0.0, where it is the identity; the
- * Python drop-in raises NotImplementedError for dropout > 0 instead of silently ignoring it.
+ * Python drop-in accepts dropout > 0 and runs such a model in eval mode (identity there, as in the reference); a training-mode
+ * call, where the reference draws masks, raises NotImplementedError instead of silently ignoring them.
  *
  * out = epilogue(im2col(A) @ W^T).  M = batch*hout*wout rows.  Replaces nn.Conv2d 3x3/1x1 and nn.Linear
  * as called from ResnetBlock (unet.py:698-731), TransformerModel (:508,:521), Attention (:655-656,:683),

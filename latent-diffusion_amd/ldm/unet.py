@@ -264,8 +264,22 @@ class _HipModule(nn.Module):
         """Drop the derived filters (after writing parameters in a way torch cannot see)."""
         self.__dict__.pop("_ldm_cache", None)
 
+    def _active_dropout(self) -> float:
+        """Largest dropout probability of this module and its children (constructor arguments; unet.py:707, :636-639, :579)."""
+        p = self.__dict__.get("_ldm_dropout_p")
+        if p is None:
+            p = max([float(getattr(m, "dropout_p", 0.0)) for m in self.modules()] + [0.0])
+            self.__dict__["_ldm_dropout_p"] = p
+        return p
+
     def _check_call(self, x: torch.Tensor, *others) -> bool:
         """Validates the call; True when autograd is recording and the training form must run."""
+        # nn.Dropout(p) is the identity in eval mode, so a model BUILT with dropout > 0 samples correctly here; in training
+        # mode the reference draws masks (also under no_grad): there is no kernel for that, and ignoring it would be silently
+        # wrong, so the call is refused (the reference's trainer and every default use 0.0).
+        if self.training and self._active_dropout() > 0.0:
+            raise NotImplementedError("ldm_amd: dropout > 0 is only supported in eval mode (module.eval()): the training-mode "
+                                      "masks of nn.Dropout have no kernel here; the reference trainer uses dropout = 0")
         if not x.is_cuda:
             raise RuntimeError("ldm_amd: tensors must live on an AMD GPU (there is no CPU fallback)")
         p = next(self.parameters(), None)
@@ -372,8 +386,7 @@ class ResnetBlock(_HipModule):
                  norm_num_groups: int = 32, dropout: float = 0.0):
         super().__init__()
         out_channels = in_channels if out_channels is None else out_channels
-        if dropout != 0.0:
-            raise NotImplementedError("ldm_amd: dropout > 0 is not supported (the reference trainer uses 0)")
+        self.dropout_p = float(dropout)      # layers.2 is nn.Dropout(dropout) in the reference (:707); see _check_call
         self.visual = _seq(nn.GroupNorm(norm_num_groups, in_channels), nn.Identity(),
                            nn.Conv2d(in_channels, out_channels, 3, padding=1))
         self.time = _seq(nn.Identity(), nn.Linear(temb_channels, out_channels))
@@ -410,6 +423,7 @@ class Attention(_HipModule):
                  cross_attention_dim: Optional[int] = None):
         super().__init__()
         self.query_dim, self.num_heads, self.dim_head, self.dropout = query_dim, num_heads, dim_head, dropout
+        self.dropout_p = float(dropout)      # output_proj.1 is nn.Dropout(dropout) in the reference (:636-639)
         self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else query_dim
         self.inner_dim = dim_head * num_heads
         self.q_proj = nn.Linear(query_dim, self.inner_dim, bias=False)
@@ -461,6 +475,7 @@ class TransformerBlock(_HipModule):
                  activation_fn: str = "geglu", feed_forward_mult: int = 4):
         super().__init__()
         assert in_channels % num_attention_heads == 0, "in_channels must be divisible by num_attention_heads"
+        self.dropout_p = float(dropout)      # feed_forward.2 is nn.Dropout(dropout) in the reference (:579)
         self.attention_head_dim = in_channels // num_attention_heads
         self.norm1 = nn.LayerNorm(in_channels)
         self.norm2 = nn.LayerNorm(in_channels)

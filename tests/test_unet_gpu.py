@@ -103,6 +103,23 @@ def test_small_unet_fp32(golden):
         assert e32 < 2e-4  # two float32 evaluations, each on the noise floor
 
 
+def test_small_unet_built_with_dropout_is_the_same_function_in_eval_mode():
+    """nn.Dropout is the identity in eval mode (unet.py:707, :636-639, :579): a network built with dropout > 0 has the same
+    state dict and, after .eval(), the same outputs bit for bit; in training mode the call is refused."""
+    from ldm.unet import UNet
+    net, _, sd = _small_unet()
+    drop = UNet(dropout=0.1, **SMALL)
+    drop.load_state_dict(sd)
+    drop = drop.cuda()
+    x, ctx = seeded((2, 4, 32, 32), 11).cuda(), seeded((2, 77, 768), 12).cuda()
+    t = torch.tensor([999, 20]).cuda()
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError):
+            drop(x, t, ctx)
+        drop.eval()
+        assert torch.equal(drop(x, t, ctx), net(x, t, ctx))
+
+
 def test_small_unet_timestep_forms(golden):
     g = golden("unet_small.npz")
     net, _, _ = _small_unet()

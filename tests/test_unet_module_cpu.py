@@ -96,3 +96,26 @@ def test_public_names_of_the_reference_modules():
     net2 = net.to(memory_format=torch.channels_last)
     assert net2 is net and net.conv_in.weight.is_contiguous()
     assert net.up_blocks[0].upsample.weight.is_contiguous()
+
+
+def test_dropout_is_accepted_and_refused_only_where_it_would_act():
+    """nn.Dropout(p) sits in ResnetBlock.layers, Attention.output_proj and the feed-forward (unet.py:707, :636-639, :579).  It is
+    the identity in eval mode, so a model built with dropout > 0 must construct, load and sample; in training mode the
+    reference draws masks, for which there is no kernel: that call is refused instead of silently ignored (checked before
+    the device check, so it shows on a CPU tensor)."""
+    from ldm import unet as U
+    x = torch.zeros(1, 32, 8, 8)
+    for mod, args in ((U.ResnetBlock(32, 32, 64, 8, dropout=0.1), (x, torch.zeros(1, 64))),
+                      (U.Attention(32, 4, 8, dropout=0.1), (torch.zeros(1, 16, 32),)),
+                      (U.TransformerBlock(32, 4, 48, dropout=0.1), (torch.zeros(1, 16, 32), torch.zeros(1, 5, 48))),
+                      (U.UNet(block_out_channels=[32, 64, 64, 64], dropout=0.2), (torch.zeros(1, 4, 8, 8), 3, torch.zeros(1, 77, 768)))):
+        assert mod._active_dropout() > 0
+        with pytest.raises(NotImplementedError, match="eval mode"):
+            mod(*args)                                    # module.training is True after construction
+        mod.eval()
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            mod(*args)                                    # past the dropout check: only the device check is left
+    plain = U.ResnetBlock(32, 32, 64, 8)
+    assert plain._active_dropout() == 0.0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        plain(x, torch.zeros(1, 64))
