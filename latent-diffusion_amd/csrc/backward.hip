@@ -42,33 +42,37 @@ sum2x2_kernel(const T* __restrict__ x, const T* __restrict__ residual, T* __rest
 // ------------------------------------------------------------------------------------ column sums
 // Two stages.  partial[(seg*slabs + slab)][n] = sum over the slab's rows; then a fold over the slabs.
 // Block = 64 chunk-lanes (512 columns) x 4 row-lanes.
-constexpr int CS_MAX_SLABS = 64;
+constexpr int CS_MAX_SLABS = 256;
 
+// Partial column sums of one slab of rows.  A workgroup covers `cb` 8-column chunks (all of them when n <= 512, else 64 per
+// blockIdx.z) x rp = 256 / cb rows per pass, so that every lane has work whatever n is (with a fixed 64 chunks per wave a
+// 320-column matrix left 24 of 64 lanes idle), four rows in flight per thread; the rp partial rows meet in LDS in a fixed order.
 template <typename T>
 __global__ void __launch_bounds__(256)
-colsum_partial_kernel(const T* __restrict__ x, long long rows_per_segment, int n, int slab_rows, float* __restrict__ partial) {
-  __shared__ float red[4][64][8];
+colsum_partial_kernel(const T* __restrict__ x, long long rows_per_segment, int n, int slab_rows, int cb, float* __restrict__ partial) {
+  __shared__ float red[256][8];
   const int slab = blockIdx.x, nslabs = gridDim.x;
   const long long seg = blockIdx.y;
-  const int tc = threadIdx.x & 63, tp = threadIdx.x >> 6;
-  const int chunk = blockIdx.z * 64 + tc;
-  const bool active = chunk * 8 < n;
+  const int rp = 256 / cb;
+  const int tp = threadIdx.x / cb, tc = threadIdx.x - tp * cb;
+  const int chunk = blockIdx.z * cb + tc;
+  const bool active = tp < rp && chunk * 8 < n;
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (active) {
     const long long r0 = (long long)slab * slab_rows;
     const long long r1 = r0 + slab_rows < rows_per_segment ? r0 + slab_rows : rows_per_segment;
     const T* base = x + (seg * rows_per_segment) * n + chunk * 8;
     long long r = r0 + tp;
-    for (; r + 12 < r1; r += 16) {          // 4 rows in flight per thread
+    for (; r + 3 * rp < r1; r += 4 * rp) {          // 4 rows in flight per thread
       float v[4][8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) load8(base + (r + 4 * u) * n, v[u]);
+      for (int u = 0; u < 4; ++u) load8(base + (r + (long long)u * rp) * n, v[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) s[e] += v[u][e];
     }
-    for (; r < r1; r += 4) {
+    for (; r < r1; r += rp) {
       float v[8];
       load8(base + r * n, v);
 #pragma unroll
@@ -76,27 +80,42 @@ colsum_partial_kernel(const T* __restrict__ x, long long rows_per_segment, int n
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) red[tp][tc][e] = s[e];
+  for (int e = 0; e < 8; ++e) red[threadIdx.x][e] = s[e];
   __syncthreads();
   if (tp == 0 && active) {
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = ((red[0][tc][e] + red[1][tc][e]) + red[2][tc][e]) + red[3][tc][e];
+    for (int e = 0; e < 8; ++e) o[e] = red[tc][e];
+    for (int q = 1; q < rp; ++q)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] += red[q * cb + tc][e];
     store8(partial + (seg * nslabs + slab) * n + chunk * 8, o);
   }
 }
 
-// out[seg][n] (+)= sum_slab partial[(seg*slabs + slab)][n]
+// out[seg][n] (+)= sum_slab partial[(seg*slabs + slab)][n].  64 columns x 4 slab groups per workgroup: a thread adds a contiguous
+// quarter of the slabs in slab order, the four quarters meet in LDS in quarter order (fixed order: deterministic).
 __global__ void __launch_bounds__(256)
 colsum_fold_kernel(const float* __restrict__ partial, int nslabs, int n, long long total, int accumulate, float* __restrict__ out) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;   // over seg*n
-  if (idx >= total) return;
-  const long long seg = idx / n;
-  const int col = (int)(idx - seg * n);
-  float v = accumulate ? out[idx] : 0.f;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const long long idx = (long long)blockIdx.x * 64 + lane;           // over seg*n
+  float v = 0.f;
+  if (idx < total) {
+    const long long seg = idx / n;
+    const int col = (int)(idx - seg * n);
+    const int per = (nslabs + 3) / 4;
+    const int s0 = grp * per, s1 = s0 + per < nslabs ? s0 + per : nslabs;
 #pragma unroll 8
-  for (int s = 0; s < nslabs; ++s) v += partial[(seg * nslabs + s) * n + col];
-  out[idx] = v;
+    for (int s = s0; s < s1; ++s) v += partial[(seg * nslabs + s) * n + col];
+  }
+  red[grp][lane] = v;
+  __syncthreads();
+  if (grp == 0 && idx < total) {
+    float r = accumulate ? out[idx] : 0.f;
+    r += ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    out[idx] = r;
+  }
 }
 
 // --------------------------------------------------------------------------------------- GLU / SiLU
@@ -546,7 +565,7 @@ extern "C" int ldm_colsum(const void* x, int dtype, long long segments, long lon
   if (segments == 0) return LDM_OK;
   LDM_REQUIRE(segments <= 65535, "ldm_colsum: more than 65535 segments");
   LDM_REQUIRE(x && out && workspace && aligned16(x) && aligned16(workspace), "ldm_colsum: null or unaligned pointer");
-  long long want = (2048 + segments - 1) / segments;
+  long long want = (4096 + segments - 1) / segments;
   long long by_work = (rows_per_segment + 63) / 64;
   int nslabs = (int)(want < by_work ? want : by_work);
   if (nslabs > CS_MAX_SLABS) nslabs = CS_MAX_SLABS;
@@ -554,14 +573,16 @@ extern "C" int ldm_colsum(const void* x, int dtype, long long segments, long lon
   const int slab_rows = (int)((rows_per_segment + nslabs - 1) / nslabs);
   nslabs = (int)((rows_per_segment + slab_rows - 1) / slab_rows);
   hipStream_t st = (hipStream_t)stream;
-  const dim3 grid(nslabs, (unsigned)segments, (n / 8 + 63) / 64);
+  const int chunks = n / 8;
+  const int cb = chunks >= 64 ? 64 : chunks;       // 8-column chunks per workgroup; 256 / cb rows per pass
+  const dim3 grid(nslabs, (unsigned)segments, (chunks + cb - 1) / cb);
   if (dtype == LDM_BF16)
-    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows_per_segment, n, slab_rows, workspace);
+    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, rows_per_segment, n, slab_rows, cb, workspace);
   else
-    hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows_per_segment, n, slab_rows, workspace);
+    hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, st, (const float*)x, rows_per_segment, n, slab_rows, cb, workspace);
   LDM_HIP_CHECK_LAUNCH("ldm_colsum(partial)");
   const long long total = segments * n;
-  hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, workspace, nslabs, n, total, accumulate, out);
+  hipLaunchKernelGGL(colsum_fold_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, workspace, nslabs, n, total, accumulate, out);
   LDM_HIP_CHECK_LAUNCH("ldm_colsum(fold)");
   return LDM_OK;
 }

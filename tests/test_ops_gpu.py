@@ -369,6 +369,13 @@ def test_colsum_and_sum2x2():
         acc = ops.colsum(x, 6)
         ops.colsum(x, 6, out=acc)
         assert rel_l2(acc, 2 * xr.sum(1)) < 2e-6
+        # every column-blocking case of the partial kernel (n / 8 chunks: 1, 40 -> 6 rows per pass, 64, 160 -> 3 z-blocks, 320 -> 5),
+        # ragged row counts, more rows than slabs x 64; same bits on a second call (fixed summation order)
+        for rows, n in ((3, 8), (4100, 320), (70000, 320), (1000, 512), (900, 1280), (257, 2560)):
+            y, yr = _q(seeded((rows, n), 4), dt)
+            got = ops.colsum(y, 1)
+            assert rel_l2(got, yr.double().sum(0)[None]) < 5e-6, (rows, n)
+            assert torch.equal(got, ops.colsum(y, 1))
         u, ur = _q(seeded((2, 6, 10, 40), 2), dt)
         r, rr = _q(seeded((2, 3, 5, 40), 3), dt)
         ref = ur.reshape(2, 3, 2, 5, 2, 40).sum((2, 4)) + rr
