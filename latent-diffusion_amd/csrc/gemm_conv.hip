@@ -102,7 +102,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* base, unsigned bytes, u
 }
 
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int PP = 0>
-__global__ void __launch_bounds__(64 * WM * WN, 2)
+__global__ void __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && BK == 32) ? 3 : 2)   // 128x128x32: three workgroups per CU (short-K GLU layers)
 conv_gemm_bf16_kernel(const ConvGemmParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int CH = BK / 8;                 // 16-byte chunks per tile row
@@ -1122,7 +1122,15 @@ static double tile_score(const ConvGemmParams& p, int BM, int BN, int blocks_per
 static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspace_bytes, int& bm, int& bn, int& bk, int& splits) {
   splits = 1;
   const bool need160 = p.rowstats != nullptr;          // row statistics are written per 80-column wave tile: BN = 160 tiles only
-  const bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
+  bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
+  // GLU projections with five K-tiles or fewer (K <= 320: the 64x64 level's feed-forward): the tile's life is set-up, first
+  // fill and a GELU-heavy epilogue, not its loop, so what pays is more workgroups per CU to overlap them: 128x128x32 fits
+  // three (96 KB of LDS, 168 registers) where 128x128x64 fits two: -6 % per launch, -0.2 ms per step (profiles/
+  // r3_glu_short_k_three_workgroups.txt).  Slower for K >= 640 and for the plain K = 320 layers.  LDM_GEMM_GLU_BK32=0: off (A/B).
+  if (glu && p.K <= 320) {
+    const char* e = getenv("LDM_GEMM_GLU_BK32");
+    if (e == nullptr || atoi(e) != 0) bk64 = false;
+  }
   if (!bk64) {
     bk = 32;
     if (p.M <= 64 * 256 && !glu) { bm = 64; bn = 64; } else { bm = 128; bn = 128; }
