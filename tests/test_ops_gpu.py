@@ -222,13 +222,18 @@ def test_ring_forms_of_the_256_row_tiles_agree_bit_for_bit(form, monkeypatch):
     res, _ = _q(seeded((8200, 320), 4), dtype)
     xs, _ = _q(seeded((700, 64), 5), dtype)
     wsh = ops.pack_weight(seeded((160, 64), 6).cuda(), dtype)
+    x2, _ = _q(seeded((300, 128), 14), dtype)                                # two and three K-tiles: the ring's prologue cases
+    w2 = ops.pack_weight(seeded((320, 128), 15).cuda(), dtype)
+    x3, _ = _q(seeded((300, 192), 16), dtype)
+    w3k = ops.pack_weight(seeded((320, 192), 17).cuda(), dtype)
 
     def run():
         return [ops.conv_gemm(a, wc, a1=s2, ksize=3, bias=bc, rowvec=rv),
                 ops.conv_gemm(xx, w3, ksize=3, stride=2, bias=bc),
                 ops.conv_gemm(xx, w3, ksize=3, upsample=True, bias=bc),
                 ops.conv_gemm(x, wl, residual=res),
-                ops.conv_gemm(xs, wsh)]                                   # one K-tile
+                ops.conv_gemm(xs, wsh),                                   # one K-tile
+                ops.conv_gemm(x2, w2), ops.conv_gemm(x3, w3k)]
     ref = run()
     monkeypatch.setenv("LDM_GEMM_PINGPONG", form)
     for got, want in zip(run(), ref):
@@ -262,7 +267,7 @@ def test_glu_epilogue_keeps_the_preactivation(act, tile, monkeypatch):
         ops.conv_gemm(x, wp, bias=bp, glu_preact=True)                      # no GLU epilogue
 
 
-@pytest.mark.parametrize("tile", [None, "64,128,2", "128,128,3", "128,160,4", "256,128,2", "64,160,8"])
+@pytest.mark.parametrize("tile", [None, "64,128,2", "128,128,3", "128,160,4", "256,128,2", "256,160,3", "64,160,8"])
 def test_split_k(tile, monkeypatch):
     """Small-M layers (the 8x8 level) split K over blockIdx.y into a lent workspace and fold deterministically:
     3x3 conv with two sources + time embedding + bias, and linear + bias + SiLU + residual into float32."""
