@@ -55,7 +55,7 @@ struct AttnGeom {
   static constexpr int KS = (D + 31) / 32;             // 32-deep contraction steps of Q K^T
   static constexpr int DK = KS * 32;
   static constexpr int DT = D / 16 + 1 - (D % 16 == 0 ? 1 : 0);  // 16-row tiles of O^T
-  static constexpr int KROW = DK * 2 + 16;             // bytes per key row of the K image (+16: bank spread)
+  static constexpr int KROW = DK * 2 + 32;             // bytes per key row of the K image: 32 (mod 64) is conflict-free for the four 16-lane groups of ds_read_b128 (+16 was 2-way)
   static constexpr int VROW = (DT % 2 == 1 ? DT : DT + 1) * 32;  // odd multiple of 32 B: tr reads conflict-free
   static constexpr int K_BYTES = 64 * KROW;
   static constexpr int V_BYTES = 64 * VROW;

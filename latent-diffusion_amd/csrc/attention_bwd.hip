@@ -4,7 +4,7 @@
 // Dl[q] = sum_j dO[q][j] O[q][j]:
 //     P = exp2(c S - L),   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - Dl) / sqrt(d),   dQ = dS K,   dK = dS^T Q.
 // No atomics (deterministic): two kernels recompute S and dP.
-//   * attn_bwd_dq_kernel: a workgroup owns 128 queries (a wave 32, as two 16-query groups) and sweeps the keys in tiles
+//   * attn_bwd_dq_kernel: a workgroup owns 128 queries (a wave 32, as two 16-query groups; 256 and four at d = 40) and sweeps the keys in tiles
 //     of 64 -- the forward kernel's shape.  Transposed orientation: S^T = K Q^T and dP^T = V dO^T give every lane one
 //     query column, so L and Dl are per-lane scalars, and dS^T packed to bf16 is directly the B operand of
 //     dQ^T += K^T dS^T (K^T fragments by transposed LDS reads of the same K image).
@@ -13,7 +13,8 @@
 //     S = Q K^T and dP = dO V^T give every lane one key column; P and dS packed to bf16 are the B operands of
 //     dV^T += dO^T P and dK^T += Q^T dS (Q^T / dO^T by transposed reads).
 // One LDS image per operand serves both the row reads (ds_read_b128, contraction over d) and the transposed reads
-// (ds_read_b64_tr_b16, contraction over rows): row pitch 2*DK + 16 bytes.
+// (ds_read_b64_tr_b16, contraction over rows): row pitch 2*DK + 32 bytes.
+// d = 40 carries -L and -Dl inside the score products (AbGeom::AUG): the loop is one exponential and one multiply per score.
 #include "common.h"
 
 namespace ldm {
@@ -39,12 +40,44 @@ struct AbGeom {
   static constexpr int KS = (D + 31) / 32;
   static constexpr int DK = KS * 32;
   static constexpr int DT = (D + 15) / 16;
-  static constexpr int ROW = DK * 2 + 16;            // bytes per image row
+  static constexpr int ROW = DK * 2 + 32;            // bytes per image row: 32 (mod 64) keeps the row reads (ds_read_b128, four
+                                                     // 16-lane groups) AND the transposed reads (two 32-lane halves) conflict-free;
+                                                     // + 16 made both 2-way (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE)
   static constexpr int IMG = 64 * ROW;               // one 64-row image
   static constexpr int CPR = D / 8;
   static constexpr int NCH = (64 * CPR + 255) / 256;
   static constexpr int NBUF = D <= 80 ? 2 : 1;       // double-buffered tiles when they fit comfortably
+  // Head dims whose padding to 32 leaves three spare columns (d = 40, 80) carry the per-row terms of the exponent INSIDE the
+  // score products, as attention32.hip does with its running maximum: the operand swept through LDS and the one held in
+  // registers get two extra columns (-hi(L), -lo(L)) x (1, 1), so the matrix core delivers c s - L (and dP - Dl) and the loop
+  // keeps one v_exp_f32 and one multiply per score.  (The plain form spends 197 / 154 vector instructions per 64 x 32 tile of
+  // the dQ / dK-dV kernel on 44 / 56 MFMAs and is bound by their issue, not by the matrix cores.)  hi + lo are two bf16
+  // terms: L to 2^-17 relative, far below what a bf16 P resolves.
+  static constexpr bool AUG = DK - D >= 3 && D <= 40;   // (d = 80 has the columns but not the registers: the dQ kernel spills)
+  static constexpr int NGQ = D == 40 ? 4 : 2;     // 16-query groups per wave of the dQ kernel: four at d = 40 (every K / V fragment read
+                                                  // from LDS feeds four MFMAs; 256 registers, two waves per SIMD: -11 % on the launch)
+  static constexpr int NGK = D > 40 ? 1 : 2;      // 16-key groups per wave of the dK/dV kernel (one for the wide heads: the accumulators of
+                                                  // two would spill; four at d = 40 need one wave per SIMD and ran 20 % slower)
+  static constexpr int AUG_KS = D / 32, AUG_FQ = (D % 32) / 8;   // where column D sits in a register fragment (element 0)
 };
+
+constexpr float AB_MASK_BIG = 30000.0f;   // exponent offset of rows that must not contribute: exp2(-30000) == 0
+
+// bf16 pair (-hi, -lo), hi + lo = x to 2^-17 relative (x finite)
+__device__ __forceinline__ uint32_t ab_neg_split(float x) {
+  const float hi = bf16_to_f32(f32_to_bf16(x));
+  return pack_bf16x2(-hi, -(x - hi));
+}
+// fragment elements times a scalar, rounded back to bf16 (the forward rounds its scaled Q the same way)
+__device__ __forceinline__ bf16x8_t ab_scale_frag(bf16x8_t z, float c) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const uint32_t w = pack_bf16x2(bf16_to_f32((bf16_t)z[e]) * c, bf16_to_f32((bf16_t)z[e + 1]) * c);
+    z[e] = (short)(w & 0xffffu);
+    z[e + 1] = (short)(w >> 16);
+  }
+  return z;
+}
 
 // The wave-uniform tile offset goes into the DESCRIPTOR (base advanced, record count shrunk), not into the instruction's
 // scalar-offset field: LLVM documents soffset as EXCLUDED from the range check of raw buffer loads, and the rows past lk
@@ -195,7 +228,8 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  constexpr int NGQ = G::NGQ;
+  const int q0 = blockIdx.x * (64 * NGQ) + wave * (16 * NGQ);
   const bf16_t* qp = static_cast<const bf16_t*>(p.q) + (size_t)b * p.lq * p.q_stride + h * D;
   const bf16_t* gp = static_cast<const bf16_t*>(p.d_o) + (size_t)b * p.lq * p.do_stride + h * D;
   const bf16_t* kp = static_cast<const bf16_t*>(p.k) + (size_t)b * p.lk * p.kv_stride + h * D;
@@ -205,20 +239,33 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
 
   for (int i = tid * 16; i < G::NBUF * 2 * G::IMG; i += 256 * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
 
-  bf16x8_t qf[2][G::KS], gf[2][G::KS];
-  float Lq[2], Dq[2];
+  bf16x8_t qf[NGQ][G::KS], gf[NGQ][G::KS];
+  float Lq[NGQ], Dq[NGQ];
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NGQ; ++g) {
     const int qi = q0 + g * 16 + fr;
     ab_load_bfrag<D>(qp, qi, p.lq, p.q_stride, fq, qf[g]);
     ab_load_bfrag<D>(gp, qi, p.lq, p.do_stride, fq, gf[g]);
     const bool ok = qi < p.lq;
     Lq[g] = ok ? p.lse[((size_t)b * p.heads + h) * p.lq + qi] : INFINITY;   // invalid queries: P = 0
     Dq[g] = ok ? p.delta[((size_t)b * p.heads + h) * p.lq + qi] : 0.f;
-  }
-  f32x4_t acc[2][G::DT];
+    if constexpr (G::AUG) {
+      // Q carries c and (-L, -1 for the mask column of K); dO carries -Dl: the K / V images hold 1.0 in those columns
 #pragma unroll
-  for (int g = 0; g < 2; ++g)
+      for (int ks = 0; ks < G::KS; ++ks) qf[g][ks] = ab_scale_frag(qf[g][ks], p.scale_log2e);
+      if (fq == G::AUG_FQ) {
+        const uint32_t wl = ab_neg_split(ok ? Lq[g] : AB_MASK_BIG), wd = ab_neg_split(Dq[g]);
+        qf[g][G::AUG_KS][0] = (short)(wl & 0xffffu);
+        qf[g][G::AUG_KS][1] = (short)(wl >> 16);
+        qf[g][G::AUG_KS][2] = (short)0xBF80;
+        gf[g][G::AUG_KS][0] = (short)(wd & 0xffffu);
+        gf[g][G::AUG_KS][1] = (short)(wd >> 16);
+      }
+    }
+  }
+  f32x4_t acc[NGQ][G::DT];
+#pragma unroll
+  for (int g = 0; g < NGQ; ++g)
 #pragma unroll
     for (int t = 0; t < G::DT; ++t) acc[g][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -231,25 +278,35 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
     stg.fetch(kp, kv_bytes, soff, kreg);
     stg.fetch(vp, kv_bytes, soff, vreg);
   };
+  const int ragged = p.lk & 63;
+  auto commit = [&](unsigned char* buf, int t) {
+    stg.commit(buf, kreg);
+    stg.commit(buf + G::IMG, vreg);
+    // keys past lk of the last, ragged tile: +BIG in the mask column (times Q's -1); the buffer is not used again
+    if (G::AUG && ragged != 0 && t == ntiles - 1 && tid < 64 && tid >= ragged)
+      *reinterpret_cast<bf16_t*>(buf + tid * G::ROW + (D + 2) * 2) = (bf16_t)(__float_as_uint(AB_MASK_BIG) >> 16);
+  };
   __syncthreads();
+  if constexpr (G::AUG) {   // the constant columns D, D + 1 of every K and V image (a commit writes columns < D only)
+    for (int i = tid; i < G::NBUF * 2 * 64; i += 256)
+      *reinterpret_cast<uint32_t*>(smem + (i >> 6) * G::IMG + (i & 63) * G::ROW + D * 2) = 0x3F803F80u;
+    __syncthreads();
+  }
   fetch(0);
-  stg.commit(smem, kreg);
-  stg.commit(smem + G::IMG, vreg);
+  commit(smem, 0);
   if (ntiles > 1) fetch(1);
   for (int t = 0; t < ntiles; ++t) {
     unsigned char* cur = smem + (G::NBUF == 2 ? (t & 1) : 0) * 2 * G::IMG;
     __syncthreads();
     if (G::NBUF == 2 && t + 1 < ntiles) {
-      unsigned char* nxt = smem + ((t + 1) & 1) * 2 * G::IMG;
-      stg.commit(nxt, kreg);
-      stg.commit(nxt + G::IMG, vreg);
+      commit(smem + ((t + 1) & 1) * 2 * G::IMG, t + 1);
       if (t + 2 < ntiles) fetch(t + 2);
     }
     const unsigned char* kimg = cur;
     const unsigned char* vimg = cur + G::IMG;
     const int t0 = t * 64;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < NGQ; ++g) {
       f32x4_t s[4], dp[4];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
@@ -266,9 +323,13 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool valid = t0 + kb * 16 + fq * 4 + r < p.lk;
-          const float pr = valid ? __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -Lq[g])) : 0.f;
-          ds[kb][r] = pr * (dp[kb][r] - Dq[g]) * p.scale;
+          if constexpr (G::AUG) {
+            ds[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]) * dp[kb][r];      // 1/sqrt(d) waits for the store
+          } else {
+            const bool valid = t0 + kb * 16 + fq * 4 + r < p.lk;
+            const float pr = valid ? __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2e, -Lq[g])) : 0.f;
+            ds[kb][r] = pr * (dp[kb][r] - Dq[g]) * p.scale;
+          }
         }
       bf16x8_t pb[2];
       ab_pack(ds, pb);
@@ -280,19 +341,19 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
     }
     if (G::NBUF == 1 && t + 1 < ntiles) {
       __syncthreads();
-      stg.commit(smem, kreg);
-      stg.commit(smem + G::IMG, vreg);
+      commit(smem, t + 1);
       if (t + 2 < ntiles) fetch(t + 2);
     }
   }
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
+  for (int g = 0; g < NGQ; ++g) {
     const int qi = q0 + g * 16 + fr;
     if (qi >= p.lq) continue;
 #pragma unroll
     for (int dt = 0; dt < G::DT; ++dt) {
       const int col = dt * 16 + fq * 4;
       if (col < D) {
+        if constexpr (G::AUG) acc[g][dt] *= p.scale;
         uint2 w;
         w.x = ab_cvt_pk_bf16(acc[g][dt][0], acc[g][dt][1]);
         w.y = ab_cvt_pk_bf16(acc[g][dt][2], acc[g][dt][3]);
@@ -304,10 +365,10 @@ attn_bwd_dq_kernel(const AttnBwdParams p) {
 
 // --------------------------------------------------------------------------------------- dK, dV
 template <int D>
-__global__ void __launch_bounds__(256, (D <= 128 ? 2 : 1))
+__global__ void __launch_bounds__(256, (D <= 128 && AbGeom<D>::NGK <= 2 ? 2 : 1))
 attn_bwd_dkv_kernel(const AttnBwdParams p) {
   using G = AbGeom<D>;
-  constexpr int NG = D > 40 ? 1 : 2;      // 16-key groups per wave: one for the wide heads (the dK/dV accumulators of two would spill)
+  constexpr int NG = G::NGK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // NBUF x (Q image, dO image, L[64], Dl[64])
   constexpr int BUF = 2 * G::IMG + 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -333,6 +394,14 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     const int ki = k0 + g * 16 + fr;
     ab_load_bfrag<D>(kp, ki, p.lk, p.kv_stride, fq, kf[g]);
     ab_load_bfrag<D>(vp, ki, p.lk, p.kv_stride, fq, vf[g]);
+    if constexpr (G::AUG) {   // K carries c; columns D, D + 1 of K and V are 1.0 (times the -L / -Dl pairs of the Q / dO images)
+#pragma unroll
+      for (int ks = 0; ks < G::KS; ++ks) kf[g][ks] = ab_scale_frag(kf[g][ks], p.scale_log2e);
+      if (fq == G::AUG_FQ) {
+        kf[g][G::AUG_KS][0] = kf[g][G::AUG_KS][1] = (short)0x3F80;
+        vf[g][G::AUG_KS][0] = vf[g][G::AUG_KS][1] = (short)0x3F80;
+      }
+    }
   }
   f32x4_t dk[NG][G::DT], dv[NG][G::DT];
 #pragma unroll
@@ -351,7 +420,7 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     sg.fetch(gp, g_bytes, (unsigned)t * 64u * p.do_stride * 2u, greg);
     if (tid < 64) {
       const int qi = t * 64 + tid;
-      lreg = qi < p.lq ? lsep[qi] : INFINITY;     // queries past lq: P = 0
+      lreg = qi < p.lq ? lsep[qi] : (G::AUG ? AB_MASK_BIG : INFINITY);     // queries past lq: P = 0
       dreg = qi < p.lq ? dlp[qi] : 0.f;
     }
   };
@@ -359,8 +428,13 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     sq.commit(buf, qreg);
     sg.commit(buf + G::IMG, greg);
     if (tid < 64) {
-      reinterpret_cast<float*>(buf + 2 * G::IMG)[tid] = lreg;
-      reinterpret_cast<float*>(buf + 2 * G::IMG + 256)[tid] = dreg;
+      if constexpr (G::AUG) {
+        *reinterpret_cast<uint32_t*>(buf + tid * G::ROW + D * 2) = ab_neg_split(lreg);
+        *reinterpret_cast<uint32_t*>(buf + G::IMG + tid * G::ROW + D * 2) = ab_neg_split(dreg);
+      } else {
+        reinterpret_cast<float*>(buf + 2 * G::IMG)[tid] = lreg;
+        reinterpret_cast<float*>(buf + 2 * G::IMG + 256)[tid] = dreg;
+      }
     }
   };
   __syncthreads();
@@ -390,14 +464,23 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
           s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(qimg, qb, ks, fr, fq), kf[g][ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab_row_frag<D>(gimg, qb, ks, fr, fq), vf[g][ks], dp, 0, 0, 0);
         }
-        const float4 l4 = *reinterpret_cast<const float4*>(lt + qb * 16 + fq * 4);
-        const float4 d4 = *reinterpret_cast<const float4*>(dlt + qb * 16 + fq * 4);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+        if constexpr (G::AUG) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lv[r]));
-          pv[qb][r] = pr;
-          ds[qb][r] = pr * (dp[r] - dl[r]) * p.scale;
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(s[r]);
+            pv[qb][r] = pr;
+            ds[qb][r] = pr * dp[r];                                         // 1/sqrt(d) waits for the store
+          }
+        } else {
+          const float4 l4 = *reinterpret_cast<const float4*>(lt + qb * 16 + fq * 4);
+          const float4 d4 = *reinterpret_cast<const float4*>(dlt + qb * 16 + fq * 4);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lv[r]));
+            pv[qb][r] = pr;
+            ds[qb][r] = pr * (dp[r] - dl[r]) * p.scale;
+          }
         }
       }
       bf16x8_t pbp[2], pbs[2];
@@ -425,6 +508,7 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
     for (int dt = 0; dt < G::DT; ++dt) {
       const int col = dt * 16 + fq * 4;
       if (col < D) {
+        if constexpr (G::AUG) dk[g][dt] *= p.scale;
         uint2 w;
         w.x = ab_cvt_pk_bf16(dk[g][dt][0], dk[g][dt][1]);
         w.y = ab_cvt_pk_bf16(dk[g][dt][2], dk[g][dt][3]);
@@ -459,9 +543,9 @@ static int launch_attn_bwd(const AttnBwdParams& p, hipStream_t st) {
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p, D);
   }
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(prep)");
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3((p.lq + 127) / 128, p.heads, p.batch), dim3(256), smem_dq, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3((p.lq + 64 * G::NGQ - 1) / (64 * G::NGQ), p.heads, p.batch), dim3(256), smem_dq, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dq)");
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((p.lk + (D > 40 ? 63 : 127)) / (D > 40 ? 64 : 128), p.heads, p.batch), dim3(256), smem_dkv, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3((p.lk + 64 * G::NGK - 1) / (64 * G::NGK), p.heads, p.batch), dim3(256), smem_dkv, st, p);
   LDM_HIP_CHECK_LAUNCH("ldm_attention_backward(dkv)");
   return LDM_OK;
 }

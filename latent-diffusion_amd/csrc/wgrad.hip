@@ -558,6 +558,49 @@ wgrad_fold_kernel(const float* __restrict__ partial, float* __restrict__ dw, int
   dw[dst] = v;
 }
 
+// The 3x3 form of the fold, laid out for the reads (they are `splits` times the writes): a wave takes 64 consecutive input
+// channels of one filter n, so each of its 9 x splits loads is one contiguous 256-byte run of the partial tile; the nine sums
+// of a lane are the nine taps of one (n, ci), contiguous in OIHW, and go out through LDS as one contiguous run per wave.
+// Same order of additions per element as wgrad_fold_kernel.
+__global__ void __launch_bounds__(256)
+wgrad_fold9_kernel(const float* __restrict__ partial, float* __restrict__ dw, int N, int K, int csrc, int splits, int accumulate,
+                   int c_off, int ctot_dst) {
+  __shared__ float tr[4][64 * 9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int n = blockIdx.y * 4 + wv, ci0 = blockIdx.x * 64, ci = ci0 + lane;
+  const bool live = n < N && ci < csrc;
+  const size_t total = (size_t)N * K;
+  const size_t dst0 = ((size_t)(n < N ? n : 0) * ctot_dst + c_off + ci0) * 9;
+  float v[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) v[t] = (live && accumulate) ? dw[dst0 + lane * 9 + t] : 0.f;
+  if (live) {
+    const float* src = partial + (size_t)n * K + ci;
+    int s = 0;
+    for (; s + 1 < splits; s += 2) {
+      float p0[9], p1[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { p0[t] = src[(size_t)s * total + t * csrc]; p1[t] = src[(size_t)(s + 1) * total + t * csrc]; }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] = (v[t] + p0[t]) + p1[t];
+    }
+    if (s < splits) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v[t] += src[(size_t)s * total + t * csrc];
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tr[wv][lane * 9 + t] = v[t];
+  __syncthreads();
+  if (n < N) {
+    const int run = min(64, csrc - ci0) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int o = t * 64 + lane;
+      if (o < run) dw[dst0 + o] = tr[wv][o];
+    }
+  }
+}
 
 // Plain-FMA weight gradient for either dtype and any channel count: the exact-float32 parity path.  One thread per
 // dW element and pixel split; the same partial buffer and fold kernel as above.  Not a speed path.
@@ -778,7 +821,10 @@ static int wgrad_run(const LdmConvGemm* d, const void* dy, float* dw, int accumu
   LDM_REQUIRE(total < (1LL << 31), "ldm_conv_wgrad: filter of %lld elements", total);
   const dim3 fgrid((unsigned)((total + 255) / 256));
   const int ftaps = d->ksize * d->ksize;
-  if (ftaps == 9)
+  if (ftaps == 9 && !getenv("LDM_WGRAD_FOLD_V1"))
+    hipLaunchKernelGGL(wgrad_fold9_kernel, dim3((p.ctot + 63) / 64, (p.N + 3) / 4), dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, p.splits,
+                       accumulate, c_off, ctot_dst);
+  else if (ftaps == 9)
     hipLaunchKernelGGL(wgrad_fold_kernel<9>, fgrid, dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, ftaps, p.splits, accumulate, c_off, ctot_dst);
   else if (ftaps == 1)
     hipLaunchKernelGGL(wgrad_fold_kernel<1>, fgrid, dim3(256), 0, st, p.partial, dw, p.N, p.K, p.ctot, ftaps, p.splits, accumulate, c_off, ctot_dst);

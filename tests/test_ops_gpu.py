@@ -312,11 +312,13 @@ def _wgrad_ref(x_nchw, dy_nchw, wshape, stride=1, upsample=False):
     (2, 64, 0, 128, 16, 16, 3, 1, False), (3, 96, 32, 72, 9, 7, 3, 1, False), (1, 320, 0, 320, 12, 10, 3, 1, False),
     (2, 64, 0, 64, 16, 16, 3, 2, False), (2, 64, 0, 40, 8, 8, 3, 1, True), (4, 128, 64, 136, 8, 8, 1, 1, False),
     (33, 40, 0, 24, 8, 8, 3, 1, False), (2, 64, 0, 320, 8, 8, 3, 1, False), (8, 64, 0, 320, 32, 32, 3, 1, False),
-    (2, 320, 0, 64, 16, 16, 1, 1, False), (1, 64, 64, 96, 24, 24, 3, 1, False)])
+    (2, 320, 0, 64, 16, 16, 1, 1, False), (1, 64, 64, 96, 24, 24, 3, 1, False), (1, 24, 0, 30, 6, 6, 3, 1, False),
+    (2, 72, 0, 18, 5, 5, 3, 1, False)])
 def test_conv_wgrad(B, c0, c1, Cout, H, W, ks, stride, up):
     """ldm_conv_wgrad against autograd of F.conv2d: 3x3 / 1x1, two sources (two passes), stride 2, upsample, ragged
     tiles, K-tiles that straddle taps, power-of-two and other extents (fast / general staging), every large-tile shape
-    (256x256, 320x256, 256x320) and enough pixels for several pixel splits."""
+    (256x256, 320x256, 256x320), enough pixels for several pixel splits, and filter counts / channel counts that leave the
+    3x3 fold's last workgroup and last wave ragged."""
     ops = _ops()
     dt = torch.bfloat16
     x, xr = _q(nhwc(seeded((B, c0, H, W), 1)), dt)
