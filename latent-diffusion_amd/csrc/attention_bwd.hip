@@ -413,28 +413,28 @@ attn_bwd_dkv_kernel(const AttnBwdParams p) {
   sq.init(tid, p.q_stride);
   sg.init(tid, p.do_stride);
   uint4 qreg[G::NCH], greg[G::NCH];
-  float lreg = 0.f, dreg = 0.f;      // threads 0..63 carry L / Dl of the tile's 64 queries
+  // L and Dl of the tile's 64 queries: wave 0 carries L, wave 1 Dl, by ONE unconditional buffer load each.  Queries past lq
+  // read 0, and so do their Q and dO rows: P = 1 meets dO = 0 and dS = 1 * (0 - 0), nothing reaches dK / dV.  (As
+  // `if (tid < 64) l = qi < lq ? lse[qi] : ...` the select's default overwrote a register that, for all the compiler
+  // could prove, still had a load in flight: it put s_waitcnt vmcnt(0) right behind the tile loads just issued, wave 0 sat
+  // out a memory latency per tile and the other three waves waited for it at the barrier -- 16 % of the kernel.)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* const ld_base = wv == 0 ? lsep : dlp;
+  const unsigned ld_off = wv < 2 ? (unsigned)lane * 4u : 0x80000000u;
+  float ldreg = 0.f;
   const int ntiles = (p.lq + 63) / 64;
   auto fetch = [&](int t) {
     sq.fetch(qp, q_bytes, (unsigned)t * 64u * p.q_stride * 2u, qreg);
     sg.fetch(gp, g_bytes, (unsigned)t * 64u * p.do_stride * 2u, greg);
-    if (tid < 64) {
-      const int qi = t * 64 + tid;
-      lreg = qi < p.lq ? lsep[qi] : (G::AUG ? AB_MASK_BIG : INFINITY);     // queries past lq: P = 0
-      dreg = qi < p.lq ? dlp[qi] : 0.f;
-    }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ld_base + t * 64), 0, (p.lq - t * 64) * 4, 0x00020000);
+    ldreg = __uint_as_float((unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)ld_off, 0, 0));
   };
   auto commit = [&](unsigned char* buf) {
     sq.commit(buf, qreg);
     sg.commit(buf + G::IMG, greg);
-    if (tid < 64) {
-      if constexpr (G::AUG) {
-        *reinterpret_cast<uint32_t*>(buf + tid * G::ROW + D * 2) = ab_neg_split(lreg);
-        *reinterpret_cast<uint32_t*>(buf + G::IMG + tid * G::ROW + D * 2) = ab_neg_split(dreg);
-      } else {
-        reinterpret_cast<float*>(buf + 2 * G::IMG)[tid] = lreg;
-        reinterpret_cast<float*>(buf + 2 * G::IMG + 256)[tid] = dreg;
-      }
+    if (wv < 2) {
+      if constexpr (G::AUG) *reinterpret_cast<uint32_t*>(buf + wv * G::IMG + lane * G::ROW + D * 2) = ab_neg_split(ldreg);
+      else reinterpret_cast<float*>(buf + 2 * G::IMG + wv * 256)[lane] = ldreg;
     }
   };
   __syncthreads();

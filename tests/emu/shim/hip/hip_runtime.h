@@ -194,6 +194,13 @@ static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int)
   if (chk + 16 <= rs.bytes) memcpy(&r, rs.base + off, 16);
   return r;
 }
+static inline unsigned raw_buffer_load_b32(rsrc_t rs, int voff, int soff, int) {
+  const unsigned long long chk = (unsigned long long)(unsigned)voff + (soff_checked() ? (unsigned)soff : 0u);
+  const unsigned long long off = (unsigned long long)(unsigned)voff + (unsigned)soff;
+  unsigned r = 0;
+  if (chk + 4 <= rs.bytes) memcpy(&r, rs.base + off, 4);
+  return r;
+}
 
 }  // namespace emu
 
@@ -201,6 +208,7 @@ static inline u32x4_emu raw_buffer_load_b128(rsrc_t rs, int voff, int soff, int)
 #define __builtin_amdgcn_make_buffer_rsrc ::emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds ::emu::raw_ptr_buffer_load_lds
 #define __builtin_amdgcn_raw_buffer_load_b128 ::emu::raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b32 ::emu::raw_buffer_load_b32
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16 ::emu::mfma_f32_16x16x32_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 ::emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 ::emu::mfma_f32_16x16x4f32
