@@ -34,6 +34,12 @@ def test_hot_kernels_have_no_spills_and_no_waterfall_loops(rows):
             # built for three workgroups per CU (168 registers): one 16-byte spill + reload in the epilogue, none in the K loop
             assert r["scratch"] <= 32 and r["scratch_ops"] <= 2, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
             continue
+        if r["kernel"].startswith("attn_bwd_dq_kernel<40>"):
+            # 64 queries per wave at two waves per SIMD (256 registers): one dword spilled before the key loop and reloaded
+            # behind it, none inside (the +11 % of the wider wave was measured with it: profiles/r3_attention_backward_ab.txt)
+            assert r["scratch"] <= 8 and r["scratch_ops"] <= 2, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
+            assert r["waterfall"] == 0, (r["kernel"], "waterfall loops", r["waterfall"])
+            continue
         assert r["scratch"] == 0 and r["scratch_ops"] == 0, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
         assert r["waterfall"] == 0, (r["kernel"], "waterfall loops", r["waterfall"])
 
