@@ -42,6 +42,10 @@ struct ConvGemmParams {
   const float* ln_s1;     //   [N]: sum_k W'[n][k] of the gamma-scaled filter this call multiplies with
   float ln_eps;
   void* glu_preact; // GLU epilogues, bf16: also store the biased pre-activation [M][N] (paired column order) -- the training forward
+  int nt_out;       // bf16 output stored with the non-temporal hint: set by the host for outputs far larger than the caches
+                    // (>= LDM_GEMM_NT_MB, default 128 MB: the 64x64 level's q|k|v and feed-forward outputs), which the next
+                    // kernel reads from HBM either way; smaller outputs keep plain stores (their consumer finds them in the
+                    // Infinity Cache: the 84 MB output of a 64x64-level conv was 3 % SLOWER with the hint)
   int splits;       // split-K: blockIdx.y takes K-tiles [y*nk/splits, (y+1)*nk/splits) and writes raw fp32 partial sums
   float* partial;   //          to partial[y][M][N]; splitk_reduce_kernel folds them and applies the epilogue
 #ifdef LDM_GEMM_STAMPS
@@ -783,7 +787,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             if (has_res) add_bf16x8(v, rres[ps]);
           }
           if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
-          else store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+          else if (p.nt_out) {
+            typedef __attribute__((ext_vector_type(4))) unsigned int v4u_t;
+            const v4u_t r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+            __builtin_nontemporal_store(r, reinterpret_cast<v4u_t*>(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps]));
+          } else {
+            store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+          }
           if (want_stats) {
             float sx = 0.f, sq = 0.f;
 #pragma unroll
@@ -1224,6 +1234,12 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   p.ln_s1 = d->ln_colsum;
   p.ln_eps = d->ln_eps;
   p.glu_preact = d->glu_preact;
+  {
+    const char* e = getenv("LDM_GEMM_NT_MB");             // read per call (tests toggle it): 0 = never, 1 = nearly always
+    const long long nt_bytes = (e ? atoll(e) : 128LL) << 20;
+    const long long out_bytes = (long long)d->batch * d->hout * d->wout * (long long)d->n * (glu ? 1 : 2);
+    p.nt_out = nt_bytes > 0 && d->out_dtype == LDM_BF16 && out_bytes >= nt_bytes;
+  }
 #ifdef LDM_GEMM_STAMPS
   p.stamps = nullptr;
   {

@@ -495,6 +495,27 @@ def test_attention_backward(B, H, Lq, Lk, d):
         assert torch.equal(fused[..., :C], dq) and torch.equal(fused[..., C:], dkv)
 
 
+def test_large_outputs_stored_with_the_nontemporal_hint_are_the_same_bits(monkeypatch):
+    """Outputs of 128 MB and more go out through non-temporal stores (LDM_GEMM_NT_MB): same values, plain and GLU epilogue,
+    with the threshold lowered so that a small case takes that path."""
+    ops = _ops()
+    dt = torch.bfloat16
+    x, _ = _q(seeded((2, 16, 16, 320), 1), dt)
+    w = seeded((1280, 320), 2) * 0.05
+    b = 0.1 * seeded((1280,), 3)
+    res, _ = _q(seeded((2, 16, 16, 1280), 4), dt)
+    wp = ops.pack_weight(w.cuda(), dt)
+    wg = ops.pack_weight(w.cuda(), dt, glu_pairs=True)
+    monkeypatch.setenv("LDM_GEMM_NT_MB", "0")
+    plain = ops.conv_gemm(x, wp, bias=b.cuda(), residual=res)
+    bg = ops.pack_weight(b.cuda(), torch.float32, glu_pairs=True).flatten()
+    gated = ops.conv_gemm(x, wg, bias=bg, glu="geglu")
+    monkeypatch.setenv("LDM_GEMM_NT_MB", "1")
+    plain_nt = ops.conv_gemm(x, wp, bias=b.cuda(), residual=res)
+    gated_nt = ops.conv_gemm(x, wg, bias=bg, glu="geglu")
+    assert torch.equal(plain, plain_nt) and torch.equal(gated, gated_nt)
+
+
 def test_conv_gemm_rejects_bad_shapes():
     ops = _ops()
     x = torch.zeros(2, 4, 4, 24, device="cuda", dtype=torch.bfloat16)  # 24 channels: not a multiple of 32
