@@ -787,12 +787,12 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
             if (has_res) add_bf16x8(v, rres[ps]);
           }
           if (out_f32) store8(static_cast<float*>(outp) + (size_t)m * nout + ocol[ps], v);
-          else if (p.nt_out) {
+          else {
             typedef __attribute__((ext_vector_type(4))) unsigned int v4u_t;
             const v4u_t r = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
-            __builtin_nontemporal_store(r, reinterpret_cast<v4u_t*>(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps]));
-          } else {
-            store8(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps], v);
+            v4u_t* const dst = reinterpret_cast<v4u_t*>(static_cast<bf16_t*>(outp) + (size_t)m * nout + ocol[ps]);
+            if (p.nt_out) __builtin_nontemporal_store(r, dst);      // only the store instruction differs
+            else *dst = r;
           }
           if (want_stats) {
             float sx = 0.f, sq = 0.f;
