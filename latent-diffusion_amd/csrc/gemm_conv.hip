@@ -767,9 +767,13 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
               for (int e = 0; e < 8; ++e) g[e] += bg[ps][e];
             }
             if constexpr (PREACT) {   // what the backward differentiates: value and gate blocks as the plain GEMM lays them out
+              // (non-temporal: nothing reads it before the backward pass)
+              typedef __attribute__((ext_vector_type(4))) unsigned int v4u_t;
               bf16_t* pa = static_cast<bf16_t*>(p.glu_preact) + (size_t)m * p.N + ncol[ps];
-              store8(pa, v);
-              store8(pa + 16, g);
+              const v4u_t rv = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+              const v4u_t rg = {pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]), pack_bf16x2(g[4], g[5]), pack_bf16x2(g[6], g[7])};
+              __builtin_nontemporal_store(rv, reinterpret_cast<v4u_t*>(pa));
+              __builtin_nontemporal_store(rg, reinterpret_cast<v4u_t*>(pa + 16));
             }
             if (epi & LDM_EPI_GEGLU) {
 #pragma unroll
