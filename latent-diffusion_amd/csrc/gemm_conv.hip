@@ -1139,8 +1139,8 @@ static void pick_tile_bf16(const ConvGemmParams& p, bool glu, long long workspac
   bool bk64 = p.ctot % 64 == 0 && p.c0 % 64 == 0;
   // GLU projections with five K-tiles or fewer (K <= 320: the 64x64 level's feed-forward): the tile's life is set-up, first
   // fill and a GELU-heavy epilogue, not its loop, so what pays is more workgroups per CU to overlap them: 128x128x32 fits
-  // three (96 KB of LDS, 168 registers) where 128x128x64 fits two: -6 % per launch, -0.2 ms per step (profiles/
-  // r3_glu_short_k_three_workgroups.txt).  Slower for K >= 640 and for the plain K = 320 layers.  LDM_GEMM_GLU_BK32=0: off (A/B).
+  // three (48 KB of LDS each on the 3-slot ring, 168 registers) where 128x128x64 fits two: -6 % per launch, -0.2 ms per step
+  // (profiles/r3_glu_short_k_three_workgroups.txt), the 3-slot ring another -5 % / -0.15 ms.  Equal at K = 640, slower at K = 1280 and for the plain K = 320 layers.  LDM_GEMM_GLU_BK32=0: off (A/B).
   if (glu && p.K <= 320) {
     const char* e = getenv("LDM_GEMM_GLU_BK32");
     if (e == nullptr || atoi(e) != 0) bk64 = false;
@@ -1313,7 +1313,13 @@ extern "C" int ldm_conv_gemm(const LdmConvGemm* d, void* stream) {
   const int key = bm * 1000000 + bn * 1000 + bk;
   switch (key) {
     case 64064032: return launch_bf16<64, 64, 32, 2, 2>(p, st);
-    case 128128032: return launch_bf16<128, 128, 32, 2, 2>(p, st);
+    case 128128032: {
+      // the short-K GLU tile on the 3-slot ring (48 KB of LDS: still three workgroups per CU, and the LDS-DMA of the tile after
+      // next stays in flight across the ONE barrier per K-tile): -5 % on the 64x64 level's feed-forward (392 -> 373 us).
+      // The same ring under 128x128x64 costs the second workgroup per CU: 286 -> 430 us.  LDM_GEMM_128_RING3=0: two slots (A/B).
+      const char* e = getenv("LDM_GEMM_128_RING3");
+      return (e == nullptr || atoi(e) != 0) ? launch_bf16<128, 128, 32, 2, 2, 3>(p, st) : launch_bf16<128, 128, 32, 2, 2>(p, st);
+    }
     case 128128064: return launch_bf16<128, 128, 64, 2, 2>(p, st);
     case 64128064: return launch_bf16<64, 128, 64, 2, 2>(p, st);
     case 128160064: return launch_bf16<128, 160, 64, 2, 2>(p, st);

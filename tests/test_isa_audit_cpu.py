@@ -31,8 +31,9 @@ def test_hot_kernels_have_no_spills_and_no_waterfall_loops(rows):
     assert len(hot) >= 30, [r["kernel"] for r in hot]
     for r in hot:
         if r["kernel"].startswith("conv_gemm_bf16_kernel<128, 128, 32,"):
-            # built for three workgroups per CU (168 registers): one 16-byte spill + reload in the epilogue, none in the K loop
-            assert r["scratch"] <= 32 and r["scratch_ops"] <= 2, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
+            # built for three workgroups per CU (168 registers): at most 16 bytes spilled and reloaded in the epilogue (two
+            # stores + two loads in the 3-slot form), none in the K loop
+            assert r["scratch"] <= 32 and r["scratch_ops"] <= 4, (r["kernel"], "spills", r["scratch"], r["scratch_ops"])
             continue
         if r["kernel"].startswith("attn_bwd_dq_kernel<40>"):
             # 64 queries per wave at two waves per SIMD (256 registers): one dword spilled before the key loop and reloaded
