@@ -462,7 +462,8 @@ def test_layernorm_backward(dtype, rows, cols):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,d", [(2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (2, 4, 128, 128, 80), (1, 8, 70, 77, 80),
-                                         (2, 2, 64, 64, 160), (1, 8, 100, 300, 160), (1, 2, 130, 190, 64)])
+                                         (2, 2, 64, 64, 160), (1, 8, 100, 300, 160), (1, 2, 130, 190, 64),
+                                         (1, 2, 70, 45, 40), (2, 2, 257, 129, 40), (1, 1, 33, 17, 40)])
 def test_attention_backward(B, H, Lq, Lk, d):
     """Flash backward (dq; dk, dv) against autograd of F.scaled_dot_product_attention in float32 on the same
     bf16-rounded operands; also the lse the training forward saves."""
