@@ -567,8 +567,12 @@ conv_gemm_bf16_kernel(const ConvGemmParams p) {
       }
       wait_older_dma(nk > 1);                 // tile 0 (tile 1 may still be in flight)
       barrier();
+      LDM_STAMP(2);                           // (diagnostic build) first tile landed for every wave
       if (wave < WM * WN / 2) {
         for (int kt = 0; kt < nk; ++kt) {
+          if (kt == 1) LDM_STAMP(12);          // (diagnostic build) starts of K-tiles 1, 2, 3: what a short-K tile's loop is made of
+          if (kt == 2) LDM_STAMP(13);
+          if (kt == 3) LDM_STAMP(14);
           if (kt == 8) LDM_STAMP(8);
           read_frags(slot);
           const bool more = kt + 2 < nk;

@@ -68,6 +68,10 @@ def main():
         if (st[:, 8] != 0).all():   # K-tile 8 of the main loop: the four sub-phases between stamps 8..11
             di = np.median(np.diff(st[:, 8:12], axis=1).astype(np.float64), axis=0)
             inner = f" | kt8: {di[0]:5.0f} {di[1]:5.0f} {di[2]:5.0f}"
+        if (st[:, 12] != 0).all() and (st[:, 2] != 0).all():   # ping-pong tiles: starts of K-tiles 1..3 after the first-tile barrier (stamp 2)
+            pts = [st[:, 2]] + [st[:, c] for c in (12, 13, 14) if (st[:, c] != 0).all()]
+            dd = [np.median((b_ - a_).astype(np.float64)) for a_, b_ in zip(pts[:-1], pts[1:])]
+            inner += " | first K-tiles: " + " ".join(f"{v:5.0f}" for v in dd)
         print(f"{name:28s} {tile:>10s} {len(st):6d} | {med[0]:6.0f} {med[1]:6.0f} {med[2]:7.0f} {med[2] / (K // bk):6.0f} {med[3]:6.0f} "
               f"{tot:7.0f} | {span * 1e6:7.1f} {busy / span / 256:5.2f} {clk:6.2f}{inner}", flush=True)
 
